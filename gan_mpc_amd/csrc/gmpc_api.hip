@@ -1,0 +1,567 @@
+// C-ABI entry points of libgan_mpc_amd.so (declared in include/gan_mpc_amd.h).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "gmpc_device.h"
+
+// launchers defined in the kernel translation units ---------------------------------------------
+void gmpc_launch_rollout(const TrajArgs&, hipStream_t);
+void gmpc_launch_linesearch(const TrajArgs&, hipStream_t);
+void gmpc_launch_masks(int, int, int, int, const MlpDesc&, const float*, const float*, uint32_t*,
+                       hipStream_t);
+int gmpc_launch_linearize(int, int, int, int, const MlpDesc&, const uint32_t*, const int*, float*,
+                          hipStream_t);
+int gmpc_launch_terminal(int, int, int, const MlpDesc&, const float*, const float*, const int*,
+                         float*, float*, hipStream_t);
+void gmpc_launch_riccati(const RiccatiArgs&, hipStream_t);
+size_t gmpc_riccati_lds_bytes(int n, int m);
+void gmpc_launch_transpose(int, int, const float*, float*, hipStream_t);
+void gmpc_launch_lstm_fwd(int, const CriticDesc&, const float*, float*, float*, float*, float*,
+                          hipStream_t);
+void gmpc_launch_head(int, const CriticDesc&, int, const float*, const float*, float*, float*,
+                      float*, float*, float*, int, hipStream_t);
+void gmpc_launch_lstm_bwd(int, const CriticDesc&, const float*, const float*, const float*, float*,
+                          float*, hipStream_t);
+void gmpc_launch_wgrad(int, int, int, const float*, int, const float*, int, float*, float*, int,
+                       float*, int, hipStream_t);
+void gmpc_launch_sum(int, const float*, float*, int, hipStream_t);
+void gmpc_launch_adam(long, float*, const float*, float*, float*, float, int, float, float, float,
+                      float, float, float*, hipStream_t);
+void gmpc_launch_l2loss(int, int, int, const float*, const float*, float*, float*, hipStream_t);
+void gmpc_launch_bvec(int, int, int, int, const float*, const float*, float*, hipStream_t);
+void gmpc_launch_costvjp(int, int, int, int, const MlpDesc&, const float*, float, const float*,
+                         const float*, const float*, const float*, const float*, float*, float*,
+                         float*, int, hipStream_t);
+
+// error handling -------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(GMPC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                  __LINE__);                                                                \
+  } while (0)
+
+extern "C" const char* gmpc_last_error(void) { return g_err; }
+extern "C" const char* gmpc_version(void) { return "gan_mpc_amd 0.1 (gfx950)"; }
+
+static long mlp_count(int L, const int* dims) {
+  long c = 0;
+  for (int l = 0; l < L; ++l) c += (long)dims[l] * dims[l + 1] + dims[l + 1];
+  return c;
+}
+
+static int check_shape(const gmpc_shape* s) {
+  if (!s) return fail(GMPC_EINVAL, "shape is null");
+  if (s->n < 1 || s->m < 1 || s->T < 1) return fail(GMPC_EINVAL, "n, m, T must be positive");
+  if (s->n > 64 || s->m > 32)
+    return fail(GMPC_EINVAL,
+                "unsupported shape n=%d m=%d: this build implements the small-state path "
+                "(n <= 64, m <= 32); the large-n Riccati path is not built yet", s->n, s->m);
+  if (GMPC_TB * s->m > GMPC_THREADS) return fail(GMPC_EINVAL, "m too large");
+  if (s->dyn_layers < 2 || s->dyn_layers > GMPC_MAX_LAYERS)
+    return fail(GMPC_EINVAL, "dyn_layers must be in [2, %d]", GMPC_MAX_LAYERS);
+  if (s->cost_layers < 1 || s->cost_layers > GMPC_MAX_LAYERS)
+    return fail(GMPC_EINVAL, "cost_layers must be in [1, %d]", GMPC_MAX_LAYERS);
+  if (s->dyn_dims[0] != s->n + s->m || s->dyn_dims[s->dyn_layers] != s->n)
+    return fail(GMPC_EINVAL, "dyn_dims must start with n+m and end with n");
+  if (s->cost_dims[0] != s->n) return fail(GMPC_EINVAL, "cost_dims must start with n");
+  if (s->cost_dims[s->cost_layers] > 32)
+    return fail(GMPC_EINVAL, "cost fout must be <= 32");
+  for (int l = 1; l < s->dyn_layers; ++l)
+    if (s->dyn_dims[l] < 1 || s->dyn_dims[l] > GMPC_THREADS)
+      return fail(GMPC_EINVAL, "dynamics hidden width must be in [1, %d]", GMPC_THREADS);
+  for (int l = 1; l < s->cost_layers; ++l)
+    if (s->cost_dims[l] < 1 || s->cost_dims[l] > GMPC_THREADS)
+      return fail(GMPC_EINVAL, "cost hidden width must be in [1, %d]", GMPC_THREADS);
+  if (s->lstm_features != 0) {
+    if (s->lstm_features != 64)
+      return fail(GMPC_EINVAL, "critic lstm_features must be 64 (4F == workgroup size)");
+    if (s->head_layers < 1 || s->head_layers > GMPC_MAX_LAYERS)
+      return fail(GMPC_EINVAL, "head_layers must be in [1, %d]", GMPC_MAX_LAYERS);
+    if (s->head_dims[0] != s->lstm_features || s->head_dims[s->head_layers] != 1)
+      return fail(GMPC_EINVAL, "head_dims must start with F and end with 1");
+    for (int l = 1; l < s->head_layers; ++l)
+      if (s->head_dims[l] < 1 || s->head_dims[l] > GMPC_THREADS)
+        return fail(GMPC_EINVAL, "head hidden width must be in [1, %d]", GMPC_THREADS);
+  }
+  return 0;
+}
+
+extern "C" long gmpc_param_count(const gmpc_shape* s, int which) {
+  if (!s) return -1;
+  if (which == 0) return mlp_count(s->dyn_layers, s->dyn_dims);
+  if (which == 1) return mlp_count(s->cost_layers, s->cost_dims);
+  if (which == 2) {
+    const long F = s->lstm_features;
+    return (long)s->n * 4 * F + F * 4 * F + 4 * F + mlp_count(s->head_layers, s->head_dims);
+  }
+  return -1;
+}
+
+struct gmpc_ctx {
+  gmpc_shape sh;
+  int maxB, device;
+  std::vector<void*> allocs;
+  // bound parameters
+  const float* mpc_w = nullptr;
+  MlpDesc dyn{}, cost{};
+  float *dynT = nullptr, *costT = nullptr;
+  bool params_set = false;
+  // trajectory workspace
+  uint32_t *masks, *maskc;
+  float *Xc, *Uc, *AB, *QT, *qT;
+  float *Xs, *Us, *goals, *Ks, *ks, *grads, *adjs;
+  float *obj, *alpha, *obj_step, *U_step;
+  int *iters, *cont;
+  int solB = 0;
+  // bilevel workspace
+  float *lx, *Bvec, *Hout, *dX, *gmpc, *cact, *cdel, *bl_loss;
+  int cstride;
+  // critic workspace
+  float *critT, *gates, *cs, *hp, *hT, *dz, *hacts, *hdels, *dhT, *cscore, *closs;
+  int hstride;
+  // shared scratch
+  float *wpart, *scratch;
+  long wpart_floats;
+};
+
+template <typename Tp>
+static int dalloc(gmpc_ctx* c, Tp** p, size_t count) {
+  void* q = nullptr;
+  if (count == 0) count = 1;
+  hipError_t e = hipMalloc(&q, count * sizeof(Tp));
+  if (e != hipSuccess)
+    return fail(GMPC_ENOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(Tp),
+                hipGetErrorString(e));
+  c->allocs.push_back(q);
+  *p = static_cast<Tp*>(q);
+  return 0;
+}
+#define TRY(expr) do { int r_ = (expr); if (r_ != 0) return r_; } while (0)
+
+static void bind_mlp(MlpDesc& d, int L, const int* dims, const float* flat, float* flatT) {
+  d.L = L;
+  for (int l = 0; l <= L; ++l) d.dims[l] = dims[l];
+  long off = 0;
+  for (int l = 0; l < L; ++l) {
+    d.W[l] = flat + off;
+    d.WT[l] = flatT ? flatT + off : nullptr;
+    off += (long)dims[l] * dims[l + 1];
+    d.b[l] = flat + off;
+    off += dims[l + 1];
+  }
+}
+
+static void transpose_mlp(const MlpDesc& d, hipStream_t s) {
+  for (int l = 0; l < d.L; ++l)
+    gmpc_launch_transpose(d.dims[l], d.dims[l + 1], d.W[l], const_cast<float*>(d.WT[l]), s);
+}
+
+extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, gmpc_ctx** out) {
+  if (!out) return fail(GMPC_EINVAL, "out is null");
+  *out = nullptr;
+  TRY(check_shape(shape));
+  if (max_batch < 1) return fail(GMPC_EINVAL, "max_batch must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(GMPC_ENODEV, "no HIP device is visible; libgan_mpc_amd has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(GMPC_EINVAL, "device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  gmpc_ctx* c = new (std::nothrow) gmpc_ctx();
+  if (!c) return fail(GMPC_ENOMEM, "out of host memory");
+  c->sh = *shape;
+  c->maxB = max_batch;
+  c->device = device;
+  const gmpc_shape& s = c->sh;
+  const size_t B = max_batch, n = s.n, m = s.m, T = s.T, nm = n + m, Lh = s.dyn_layers - 1;
+  int rc = 0;
+#define A_(p, cnt) if (!rc) rc = dalloc(c, &c->p, (cnt))
+  A_(dynT, mlp_count(s.dyn_layers, s.dyn_dims));
+  A_(costT, mlp_count(s.cost_layers, s.cost_dims));
+  A_(masks, B * T * Lh * GMPC_MW);
+  A_(maskc, B * T * Lh * GMPC_MW);
+  A_(Xc, B * (T + 1) * n);
+  A_(Uc, B * T * m);
+  A_(AB, B * T * n * nm);
+  A_(QT, B * n * n);
+  A_(qT, B * n);
+  A_(Xs, B * (T + 1) * n);
+  A_(Us, B * T * m);
+  A_(goals, B * (T + 1) * n);
+  A_(Ks, B * T * m * n);
+  A_(ks, B * T * m);
+  A_(grads, B * T * m);
+  A_(adjs, B * (T + 1) * n);
+  A_(obj, B); A_(alpha, B); A_(obj_step, B); A_(U_step, B);
+  A_(iters, B); A_(cont, B);
+  // bilevel
+  int cin = 0, cout_ = 0;
+  for (int l = 0; l < s.cost_layers; ++l) { cin += s.cost_dims[l]; cout_ += s.cost_dims[l + 1]; }
+  c->cstride = cin > cout_ ? cin : cout_;
+  A_(lx, B * (T + 1) * n);
+  A_(Bvec, B * T * m);
+  A_(Hout, B * T * m);
+  A_(dX, B * (T + 1) * n);
+  A_(gmpc, B * 3);
+  A_(cact, 2 * B * c->cstride);
+  A_(cdel, 2 * B * c->cstride);
+  A_(bl_loss, B);
+  // critic
+  long wmax = 0;
+  for (int l = 0; l < s.cost_layers; ++l) {
+    long w = (long)s.cost_dims[l] * s.cost_dims[l + 1] + s.cost_dims[l + 1];
+    if (w > wmax) wmax = w;
+  }
+  c->hstride = 1;
+  if (s.lstm_features > 0) {
+    const size_t Bc = 2 * B, F = s.lstm_features, T1 = T + 1;
+    int hin = 0, hout = 0;
+    for (int l = 0; l < s.head_layers; ++l) { hin += s.head_dims[l]; hout += s.head_dims[l + 1]; }
+    c->hstride = hin > hout ? hin : hout;
+    A_(critT, (n + F) * 4 * F + mlp_count(s.head_layers, s.head_dims));
+    A_(gates, Bc * T1 * 4 * F);
+    A_(cs, Bc * T1 * F);
+    A_(hp, Bc * T1 * F);
+    A_(hT, Bc * F);
+    A_(dz, Bc * T1 * 4 * F);
+    A_(hacts, Bc * c->hstride);
+    A_(hdels, Bc * c->hstride);
+    A_(dhT, Bc * F);
+    A_(cscore, Bc);
+    A_(closs, Bc);
+    long w = (long)F * 4 * F + 4 * F;
+    if (w > wmax) wmax = w;
+    for (int l = 0; l < s.head_layers; ++l) {
+      w = (long)s.head_dims[l] * s.head_dims[l + 1] + s.head_dims[l + 1];
+      if (w > wmax) wmax = w;
+    }
+  }
+  c->wpart_floats = 256 * wmax;
+  A_(wpart, c->wpart_floats);
+  A_(scratch, 1024);
+#undef A_
+  if (rc) {
+    gmpc_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+extern "C" int gmpc_destroy(gmpc_ctx* c) {
+  if (!c) return 0;
+  for (void* p : c->allocs) (void)hipFree(p);
+  delete c;
+  return 0;
+}
+
+extern "C" int gmpc_set_params(gmpc_ctx* c, const float* mpc_w, const float* dyn, const float* cost,
+                               void* stream) {
+  if (!c || !mpc_w || !dyn || !cost) return fail(GMPC_EINVAL, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  HIP_TRY(hipSetDevice(c->device));
+  c->mpc_w = mpc_w;
+  bind_mlp(c->dyn, c->sh.dyn_layers, c->sh.dyn_dims, dyn, c->dynT);
+  bind_mlp(c->cost, c->sh.cost_layers, c->sh.cost_dims, cost, c->costT);
+  transpose_mlp(c->dyn, s);
+  transpose_mlp(c->cost, s);
+  HIP_TRY(hipGetLastError());
+  c->params_set = true;
+  return 0;
+}
+
+static int check_call(gmpc_ctx* c, int B) {
+  if (!c) return fail(GMPC_EINVAL, "ctx is null");
+  if (!c->params_set) return fail(GMPC_EINVAL, "gmpc_set_params has not been called");
+  if (B < 1 || B > c->maxB) return fail(GMPC_EINVAL, "B=%d outside [1, max_batch=%d]", B, c->maxB);
+  if (hipSetDevice(c->device) != hipSuccess) return fail(GMPC_EHIP, "hipSetDevice failed");
+  return 0;
+}
+
+static TrajArgs base_traj(gmpc_ctx* c, int B, const float* goal) {
+  TrajArgs a;
+  memset(&a, 0, sizeof(a));
+  a.B = B; a.n = c->sh.n; a.m = c->sh.m; a.T = c->sh.T;
+  a.dyn = c->dyn; a.cost = c->cost; a.mpc_w = c->mpc_w; a.goal = goal;
+  return a;
+}
+
+extern "C" int gmpc_rollout_cost(gmpc_ctx* c, int B, const float* x0, const float* U,
+                                 const float* goal, float* X, float* costs, void* stream) {
+  TRY(check_call(c, B));
+  if (!x0 || !U || !goal || !X) return fail(GMPC_EINVAL, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TrajArgs a = base_traj(c, B, goal);
+  a.x0 = x0; a.U = U; a.X = X; a.costs = costs; a.obj = c->obj; a.masks = c->masks;
+  gmpc_launch_rollout(a, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// linearise + terminal quadratisation + Riccati/adjoint sweep on (X, U)
+static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, const float* goal,
+                         const int* active, float* K, float* k, float* grad, float* adj, float* AB,
+                         int* cont, const gmpc_ilqr_opts* opts, hipStream_t s) {
+  const gmpc_shape& sh = c->sh;
+  if (gmpc_launch_linearize(B, sh.T, sh.n, sh.m, c->dyn, c->masks, active, AB, s) != 0)
+    return fail(GMPC_EINVAL, "linearize: unsupported row count for n=%d", sh.n);
+  if (gmpc_launch_terminal(B, sh.T, sh.n, c->cost, c->mpc_w, X, active, c->QT, c->qT, s) != 0)
+    return fail(GMPC_EINVAL, "terminal: unsupported fout");
+  RiccatiArgs r;
+  memset(&r, 0, sizeof(r));
+  r.B = B; r.n = sh.n; r.m = sh.m; r.T = sh.T; r.mode = 0;
+  r.X = X; r.U = U; r.goal = goal; r.mpc_w = c->mpc_w; r.AB = AB; r.QT = c->QT; r.qT = c->qT;
+  r.active = active; r.K = K; r.k = k; r.grad = grad; r.adj = adj;
+  if (cont) {
+    r.cont = cont; r.iters = c->iters; r.obj = c->obj; r.alpha = c->alpha;
+    r.obj_step = c->obj_step; r.U_step = c->U_step; r.opts = *opts;
+  }
+  gmpc_launch_riccati(r, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmpc_lqr_backward(gmpc_ctx* c, int B, const float* X, const float* U,
+                                 const float* goal, float* K, float* k, float* grad,
+                                 float* adjoints, float* AB, void* stream) {
+  TRY(check_call(c, B));
+  if (!X || !U || !goal) return fail(GMPC_EINVAL, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // relu masks at (X, U): recomputed so that any trajectory may be passed
+  gmpc_launch_masks(B, c->sh.n, c->sh.m, c->sh.T, c->dyn, X, U, c->masks, s);
+  return backward_pass(c, B, X, U, goal, nullptr, K ? K : c->Ks, k ? k : c->ks, grad, adjoints,
+                       AB ? AB : c->AB, nullptr, nullptr, s);
+}
+
+// Same as gmpc_lqr_backward but reuses the relu masks the preceding gmpc_rollout_cost of this ctx
+// produced for exactly this (X, U) -- the rollout+backward "step" timed by bench.py.
+extern "C" int gmpc_lqr_backward_after_rollout(gmpc_ctx* c, int B, const float* X, const float* U,
+                                               const float* goal, float* K, float* k, float* grad,
+                                               float* adjoints, float* AB, void* stream) {
+  TRY(check_call(c, B));
+  if (!X || !U || !goal) return fail(GMPC_EINVAL, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return backward_pass(c, B, X, U, goal, nullptr, K ? K : c->Ks, k ? k : c->ks, grad, adjoints,
+                       AB ? AB : c->AB, nullptr, nullptr, s);
+}
+
+extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float* U_init,
+                               const float* goal, const gmpc_ilqr_opts* opts, float* X, float* U,
+                               float* obj, float* grad, float* adjoints, int* iterations,
+                               void* stream) {
+  TRY(check_call(c, B));
+  if (!x0 || !U_init || !goal || !opts) return fail(GMPC_EINVAL, "null argument");
+  if (opts->make_psd) return fail(GMPC_EINVAL, "make_psd=1 is not on the reference path");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const gmpc_shape& sh = c->sh;
+  const size_t n = sh.n, m = sh.m, T = sh.T;
+  HIP_TRY(hipMemcpyAsync(c->Us, U_init, B * T * m * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemcpyAsync(c->goals, goal, B * (T + 1) * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipMemsetAsync(c->iters, 0, B * sizeof(int), s));
+  // alpha = alpha_0, steps = +inf
+  std::vector<float> init(3 * (size_t)B);
+  for (int b = 0; b < B; ++b) {
+    init[b] = opts->alpha_0;
+    init[B + b] = INFINITY;
+    init[2 * (size_t)B + b] = INFINITY;
+  }
+  HIP_TRY(hipMemcpyAsync(c->alpha, init.data(), B * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(c->obj_step, init.data() + B, B * sizeof(float), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(c->U_step, init.data() + 2 * (size_t)B, B * sizeof(float),
+                         hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));  // `init` goes out of scope below
+  TrajArgs a = base_traj(c, B, c->goals);
+  a.x0 = x0; a.U = c->Us; a.X = c->Xs; a.costs = nullptr; a.obj = c->obj; a.masks = c->masks;
+  gmpc_launch_rollout(a, s);
+  TRY(backward_pass(c, B, c->Xs, c->Us, c->goals, nullptr, c->Ks, c->ks, c->grads, c->adjs, c->AB,
+                    c->cont, opts, s));
+  TrajArgs ls = base_traj(c, B, c->goals);
+  ls.X = c->Xs; ls.Uio = c->Us; ls.obj = c->obj; ls.masks = c->masks; ls.Kg = c->Ks; ls.kg = c->ks;
+  ls.Xc = c->Xc; ls.Uc = c->Uc; ls.maskc = c->maskc; ls.active = c->cont; ls.alpha = c->alpha;
+  ls.obj_step = c->obj_step; ls.U_step = c->U_step; ls.iters = c->iters;
+  ls.alpha_0 = opts->alpha_0; ls.alpha_min = opts->alpha_min;
+  std::vector<int> hcont(B);
+  for (int it = 0; it < opts->maxiter; ++it) {
+    // stop as soon as every trajectory has stopped (one small readback per iteration)
+    HIP_TRY(hipMemcpyAsync(hcont.data(), c->cont, B * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    bool any = false;
+    for (int b = 0; b < B; ++b) any |= hcont[b] != 0;
+    if (!any) break;
+    gmpc_launch_linesearch(ls, s);
+    TRY(backward_pass(c, B, c->Xs, c->Us, c->goals, c->cont, c->Ks, c->ks, c->grads, c->adjs, c->AB,
+                      c->cont, opts, s));
+  }
+  c->solB = B;
+  if (X) HIP_TRY(hipMemcpyAsync(X, c->Xs, B * (T + 1) * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (U) HIP_TRY(hipMemcpyAsync(U, c->Us, B * T * m * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (obj) HIP_TRY(hipMemcpyAsync(obj, c->obj, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (grad) HIP_TRY(hipMemcpyAsync(grad, c->grads, B * T * m * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (adjoints)
+    HIP_TRY(hipMemcpyAsync(adjoints, c->adjs, B * (T + 1) * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (iterations)
+    HIP_TRY(hipMemcpyAsync(iterations, c->iters, B * sizeof(int), hipMemcpyDeviceToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return 0;
+}
+
+// critic ---------------------------------------------------------------------------------------
+static int bind_critic(gmpc_ctx* c, const float* critic, CriticDesc& cd, hipStream_t s) {
+  const gmpc_shape& sh = c->sh;
+  if (sh.lstm_features <= 0) return fail(GMPC_EINVAL, "this ctx was created without a critic");
+  const long n = sh.n, F = sh.lstm_features;
+  cd.n = sh.n; cd.F = sh.lstm_features; cd.T1 = sh.T + 1;
+  cd.Wcat = critic;
+  cd.WcatT = c->critT;
+  cd.b = critic + (n + F) * 4 * F;
+  bind_mlp(cd.head, sh.head_layers, sh.head_dims, critic + (n + F) * 4 * F + 4 * F,
+           c->critT + (n + F) * 4 * F);
+  gmpc_launch_transpose((int)(n + F), (int)(4 * F), cd.Wcat, c->critT, s);
+  transpose_mlp(cd.head, s);
+  return 0;
+}
+
+static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const float* label,
+                                   const float* critic, int loss_kind, float* dxseq, bool want_wgrad,
+                                   float* grad_sum, hipStream_t s) {
+  CriticDesc cd;
+  TRY(bind_critic(c, critic, cd, s));
+  const gmpc_shape& sh = c->sh;
+  const int n = sh.n, F = sh.lstm_features, T1 = sh.T + 1;
+  gmpc_launch_lstm_fwd(Bc, cd, xseq, c->gates, c->cs, c->hp, c->hT, s);
+  gmpc_launch_head(Bc, cd, loss_kind, c->hT, label, c->cscore, c->closs, c->hacts, c->hdels, c->dhT,
+                   c->hstride, s);
+  if (dxseq || want_wgrad)
+    gmpc_launch_lstm_bwd(Bc, cd, c->gates, c->cs, c->dhT, want_wgrad ? c->dz : nullptr, dxseq, s);
+  if (want_wgrad) {
+    const int rows = Bc * T1, G4 = 4 * F;
+    float* gWx = grad_sum;
+    float* gWh = gWx + (long)n * G4;
+    float* gb = gWh + (long)F * G4;
+    gmpc_launch_wgrad(rows, n, G4, xseq, n, c->dz, G4, gWx, nullptr, 0, c->wpart, 256, s);
+    gmpc_launch_wgrad(rows, F, G4, c->hp, F, c->dz, G4, gWh, gb, rows, c->wpart, 256, s);
+    float* gh = gb + G4;
+    int aoff = 0, doff = 0;
+    for (int l = 0; l < sh.head_layers; ++l) {
+      const int M = sh.head_dims[l], N = sh.head_dims[l + 1];
+      gmpc_launch_wgrad(Bc, M, N, c->hacts + aoff, c->hstride, c->hdels + doff, c->hstride, gh,
+                        gh + (long)M * N, Bc, c->wpart, 256, s);
+      gh += (long)M * N + N;
+      aoff += M;
+      doff += N;
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmpc_critic_loss_grad(gmpc_ctx* c, int Bc, const float* xseq, const float* label,
+                                     const float* critic, float* loss_sum, float* grad_sum,
+                                     void* stream) {
+  if (!c) return fail(GMPC_EINVAL, "ctx is null");
+  if (Bc < 1 || Bc > 2 * c->maxB) return fail(GMPC_EINVAL, "Bc=%d outside [1, 2*max_batch]", Bc);
+  if (!xseq || !label || !critic || !loss_sum || !grad_sum) return fail(GMPC_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TRY(critic_forward_backward(c, Bc, xseq, label, critic, 0, nullptr, true, grad_sum, s));
+  gmpc_launch_sum(Bc, c->closs, loss_sum, 0, s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmpc_critic_score_vjp(gmpc_ctx* c, int Bc, const float* xseq, const float* critic,
+                                     float* score, float* dxseq, void* stream) {
+  if (!c) return fail(GMPC_EINVAL, "ctx is null");
+  if (Bc < 1 || Bc > 2 * c->maxB) return fail(GMPC_EINVAL, "Bc=%d outside [1, 2*max_batch]", Bc);
+  if (!xseq || !critic || !score) return fail(GMPC_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  TRY(critic_forward_backward(c, Bc, xseq, nullptr, critic, 2, dxseq, false, nullptr, s));
+  HIP_TRY(hipMemcpyAsync(score, c->cscore, Bc * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return 0;
+}
+
+// bilevel ----------------------------------------------------------------------------------------
+extern "C" int gmpc_bilevel_grad(gmpc_ctx* c, int B, int loss_kind, const float* desired,
+                                 const float* critic, float sign, float* loss, float* grad_sum,
+                                 void* stream) {
+  TRY(check_call(c, B));
+  if (c->solB != B) return fail(GMPC_EINVAL, "gmpc_ilqr_solve with B=%d must precede this call", B);
+  if (!loss || !grad_sum) return fail(GMPC_EINVAL, "null argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const gmpc_shape& sh = c->sh;
+  const int n = sh.n, m = sh.m, T = sh.T;
+  if (loss_kind == 0) {
+    if (!desired) return fail(GMPC_EINVAL, "desired is null");
+    gmpc_launch_l2loss(B, T, n, c->Xs, desired, loss, c->lx, s);
+  } else if (loss_kind == 1) {
+    if (!critic) return fail(GMPC_EINVAL, "critic is null");
+    TRY(critic_forward_backward(c, B, c->Xs, nullptr, critic, 1, c->lx, false, nullptr, s));
+    HIP_TRY(hipMemcpyAsync(loss, c->closs, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  } else {
+    return fail(GMPC_EINVAL, "loss_kind must be 0 (L2) or 1 (JS)");
+  }
+  // a8: Bvec; a9+solve: structured Hessian solve; a11: cost_vjp
+  gmpc_launch_bvec(B, T, n, m, c->AB, c->lx, c->Bvec, s);
+  RiccatiArgs r;
+  memset(&r, 0, sizeof(r));
+  r.B = B; r.n = n; r.m = m; r.T = T; r.mode = 1;
+  r.X = c->Xs; r.U = c->Us; r.goal = c->goals; r.mpc_w = c->mpc_w; r.AB = c->AB; r.QT = c->QT;
+  r.qT = c->qT; r.K = c->Ks; r.k = c->ks; r.Bvec = c->Bvec; r.Hout = c->Hout; r.dX = c->dX;
+  gmpc_launch_riccati(r, s);
+  gmpc_launch_costvjp(B, T, n, m, c->cost, c->mpc_w, sign, c->Xs, c->Us, c->goals, c->Hout, c->dX,
+                      c->gmpc, c->cact, c->cdel, c->cstride, s);
+  // sums over the batch: mpc_w (3 columns of gmpc) and the cost layers
+  gmpc_launch_wgrad(B, 1, 3, c->gmpc, 0, c->gmpc, 3, c->scratch + 512, grad_sum, B, c->wpart, 256, s);
+  float* g = grad_sum + 3;
+  int aoff = 0, doff = 0;
+  for (int l = 0; l < sh.cost_layers; ++l) {
+    const int M = sh.cost_dims[l], N = sh.cost_dims[l + 1];
+    gmpc_launch_wgrad(2 * B, M, N, c->cact + aoff, c->cstride, c->cdel + doff, c->cstride, g,
+                      g + (long)M * N, B, c->wpart, 256, s);
+    g += (long)M * N + N;
+    aoff += M;
+    doff += N;
+  }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmpc_adam_clip_step(gmpc_ctx* c, long count, float* params, const float* grad,
+                                   float* m, float* v, float grad_scale, int step, float lr,
+                                   float max_norm, float b1, float b2, float eps, void* stream) {
+  if (!c || !params || !grad || !m || !v) return fail(GMPC_EINVAL, "null argument");
+  if (count < 1 || step < 1) return fail(GMPC_EINVAL, "count and step must be positive");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  gmpc_launch_adam(count, params, grad, m, v, grad_scale, step, lr, max_norm, b1, b2, eps, c->scratch,
+                   s);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// accessors used by the bilevel parity tests and the Python mirror (device pointers, valid until the
+// next solve): 0 X, 1 U, 2 H (A^-1 B), 3 dX, 4 Bvec, 5 AB, 6 K, 7 k
+extern "C" const float* gmpc_debug_buffer(gmpc_ctx* c, int which) {
+  if (!c) return nullptr;
+  switch (which) {
+    case 0: return c->Xs; case 1: return c->Us; case 2: return c->Hout; case 3: return c->dX;
+    case 4: return c->Bvec; case 5: return c->AB; case 6: return c->Ks; case 7: return c->ks;
+    default: return nullptr;
+  }
+}

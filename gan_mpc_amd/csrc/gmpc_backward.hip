@@ -1,0 +1,562 @@
+// Backward pass of one iLQR iteration: dynamics Jacobians (reverse relu chain), terminal cost
+// quadratisation, and the fused Riccati + adjoint recursion.
+//
+// Reference arithmetic: trajax linearize / quadratize / lqr_step / tvlqr / adjoint as run inside
+// trajax ilqr (reference call sites policy/optimizers.py:19,55) on dynamics/nn.py:27-34 and
+// cost/cost_model.py:20-42, cost/nn.py:23-29.
+#include "gmpc_device.h"
+
+// ------------------------------------------------------------------------------------------------
+// k_linearize: [A_t | B_t] = I + W_L^T D_{L-1} W_{L-1}^T ... D_1 W_1^T for SP samples (b,t) per pass.
+// Rows r = sp*n + i (output coordinate i of sample sp) ride in registers as R4 float4 per thread;
+// one thread per hidden neuron; weights (transposed copies) are read coalesced and reused for all
+// rows.  AB layout [B][T][n][n+m].
+// ------------------------------------------------------------------------------------------------
+template <int R4>
+__global__ __launch_bounds__(GMPC_THREADS) void k_linearize(int B, int T, int n, int m, int SP,
+                                                            MlpDesc dyn, const uint32_t* masks,
+                                                            const int* active, float* AB) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* actA = reinterpret_cast<float4*>(smem);
+  float4* actB = actA + GMPC_THREADS * R4;
+  const int tid = threadIdx.x;
+  const int Lh = dyn.L - 1;
+  const int nm = n + m;
+  const int NSamp = B * T;
+  const int ngroups = (NSamp + SP - 1) / SP;
+  const int R = SP * n;
+
+  for (int g = blockIdx.x; g < ngroups; g += gridDim.x) {
+    const int s0 = g * SP;
+    if (active != nullptr) {
+      bool any = false;
+      for (int sp = 0; sp < SP && s0 + sp < NSamp; ++sp) any |= active[(s0 + sp) / T] != 0;
+      if (!any) continue;
+    }
+    // ---- seed: act[o][r] = W_L[o][i] * D_{L-1}[sp][o]
+    float4* in = actA;
+    float4* out = actB;
+    {
+      const int Hd = dyn.dims[Lh];
+      if (tid < Hd) {
+        const float* wl = dyn.W[Lh] + (size_t)tid * n;
+#pragma unroll
+        for (int q = 0; q < R4; ++q) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int r = q * 4 + c;
+            if (r < R) {
+              const int sp = r / n, i = r - sp * n;
+              const int s = min(s0 + sp, NSamp - 1);
+              const uint32_t w = masks[((size_t)s * Lh + (Lh - 1)) * GMPC_MW + (tid >> 5)];
+              f4set(v, c, ((w >> (tid & 31)) & 1u) ? wl[i] : 0.f);
+            }
+          }
+          in[tid * R4 + q] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- hidden-to-hidden reverse steps
+    for (int l = Lh - 1; l >= 1; --l) {
+      const int K = dyn.dims[l + 1], N = dyn.dims[l];
+      float4 acc[R4];
+#pragma unroll
+      for (int q = 0; q < R4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dense_rows<R4>(dyn.WT[l], K, N, tid, in, acc);
+      if (tid < N) {
+#pragma unroll
+        for (int q = 0; q < R4; ++q) {
+          float4 v = acc[q];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int r = q * 4 + c;
+            if (r < R) {
+              const int sp = r / n;
+              const int s = min(s0 + sp, NSamp - 1);
+              const uint32_t w = masks[((size_t)s * Lh + (l - 1)) * GMPC_MW + (tid >> 5)];
+              if (!((w >> (tid & 31)) & 1u)) f4set(v, c, 0.f);
+            }
+          }
+          out[tid * R4 + q] = v;
+        }
+      }
+      __syncthreads();
+      float4* tmp = in; in = out; out = tmp;
+    }
+    // ---- input layer: J[r][c] = sum_o act[o][r] * W_1[c][o]
+    dense_small<R4>(dyn.WT[0], dyn.dims[1], nm, in, out);
+    for (int e = tid; e < R * nm; e += blockDim.x) {
+      const int r = e / nm, c = e - r * nm;
+      const int sp = r / n, i = r - sp * n;
+      const int s = s0 + sp;
+      if (s < NSamp) {
+        const float4 v = out[c * R4 + (r >> 2)];
+        AB[((size_t)s * n + i) * nm + c] = f4get(v, r & 3) + (c == i ? 1.0f : 0.0f);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_terminal: terminal cost w2*|y(x_T)|^2 quadratised: q_T = 2 w2 Jc^T y, Q_T = 2 w2 Jc^T Jc.
+// One workgroup per trajectory; rows = the fout outputs of the cost MLP.
+// ------------------------------------------------------------------------------------------------
+template <int R4>
+__global__ __launch_bounds__(GMPC_THREADS) void k_terminal(int B, int T, int n, MlpDesc cm,
+                                                           const float* mpc_w, const float* X,
+                                                           const int* active, float* QT, float* qT) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* actA = reinterpret_cast<float4*>(smem);
+  float4* actB = actA + GMPC_THREADS * R4;
+  float* zpos = reinterpret_cast<float*>(actB + GMPC_THREADS * R4);  // [Lc][256] relu masks
+  float* yv = zpos + GMPC_MAX_LAYERS * GMPC_THREADS;                 // [fout]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  if (active != nullptr && active[b] == 0) return;
+  const int Lc = cm.L - 1;
+  const int fo = cm.dims[Lc + 1];
+  const float w2 = sigmoidf_(mpc_w[2]);
+  // forward (component .x only)
+  float4* in = actA;
+  float4* out = actB;
+  if (tid < n) in[tid] = make_float4(X[((size_t)b * (T + 1) + T) * n + tid], 0.f, 0.f, 0.f);
+  __syncthreads();
+  for (int l = 0; l < Lc; ++l) {
+    const int K = cm.dims[l], N = cm.dims[l + 1];
+    float4 acc[1] = {make_float4(tid < N ? cm.b[l][tid] : 0.f, 0.f, 0.f, 0.f)};
+    dense_rows<1>(cm.W[l], K, N, tid, in, acc);
+    if (tid < N) {
+      zpos[l * GMPC_THREADS + tid] = acc[0].x > 0.f ? 1.f : 0.f;
+      out[tid] = make_float4(fmaxf(acc[0].x, 0.f), 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    float4* tmp = in; in = out; out = tmp;
+  }
+  {
+    // output layer: fo is small, one thread per output
+    const int K = cm.dims[Lc];
+    if (tid < fo) {
+      float s = cm.b[Lc][tid];
+      for (int k = 0; k < K; ++k) s = fmaf(cm.W[Lc][(size_t)k * fo + tid], in[k].x, s);
+      yv[tid] = s;
+    }
+  }
+  __syncthreads();
+  // reverse chain with rows r = output index
+  in = actA; out = actB;
+  {
+    const int Hd = cm.dims[Lc];
+    if (tid < Hd) {
+      const float mk = Lc > 0 ? zpos[(Lc - 1) * GMPC_THREADS + tid] : 1.f;
+      const float* wl = cm.W[Lc] + (size_t)tid * fo;
+#pragma unroll
+      for (int q = 0; q < R4; ++q) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int r = q * 4 + c;
+          if (r < fo) f4set(v, c, wl[r] * mk);
+        }
+        in[tid * R4 + q] = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int l = Lc - 1; l >= 1; --l) {
+    const int K = cm.dims[l + 1], N = cm.dims[l];
+    float4 acc[R4];
+#pragma unroll
+    for (int q = 0; q < R4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dense_rows<R4>(cm.WT[l], K, N, tid, in, acc);
+    if (tid < N) {
+      const float mk = zpos[(l - 1) * GMPC_THREADS + tid];
+#pragma unroll
+      for (int q = 0; q < R4; ++q)
+        out[tid * R4 + q] = make_float4(acc[q].x * mk, acc[q].y * mk, acc[q].z * mk, acc[q].w * mk);
+    }
+    __syncthreads();
+    float4* tmp = in; in = out; out = tmp;
+  }
+  // Jc[r][i] = sum_o act[o][r] W_1[i][o]   ->  out[i*R4 + r/4].(r%4)
+  if (Lc > 0) {
+    dense_small<R4>(cm.WT[0], cm.dims[1], n, in, out);
+  } else {
+    // single Dense layer: Jc[r][i] = W[i][r]
+    for (int e = tid; e < n * R4; e += blockDim.x) {
+      const int i = e / R4, q = e - i * R4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c = 0; c < 4; ++c)
+        if (q * 4 + c < fo) f4set(v, c, cm.W[0][(size_t)i * fo + q * 4 + c]);
+      out[e] = v;
+    }
+    __syncthreads();
+  }
+  const float* J = reinterpret_cast<const float*>(out);  // J[i*4*R4 + r]
+  const int RS = 4 * R4;
+  for (int e = tid; e < n * n; e += blockDim.x) {
+    const int i = e / n, k = e - i * n;
+    float s = 0.f;
+    for (int r = 0; r < fo; ++r) s = fmaf(J[i * RS + r], J[k * RS + r], s);
+    QT[(size_t)b * n * n + e] = 2.f * w2 * s;
+  }
+  if (tid < n) {
+    float s = 0.f;
+    for (int r = 0; r < fo; ++r) s = fmaf(J[tid * RS + r], yv[r], s);
+    qT[(size_t)b * n + tid] = 2.f * w2 * s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_riccati: one wavefront per trajectory walks t = T-1 .. 0 with P, p and the adjoint in LDS and
+// emits the LQR gains (K_t, k_t), the control gradient g_t and the adjoints lambda_t.
+// mode 0 : iLQR step (trajax lqr_step with delta = 1e-8, Cholesky; q_t, r_t from the cost)
+// mode 1 : bilevel Hessian solve (no regulariser; linear term r~_t = -Bvec_t, q~ = 0); then a forward
+//          tangent roll writes H_t = dU_t and dX_t  (oracle hessian_solve).
+// ------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_riccati(RiccatiArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = a.n, m = a.m, T = a.T, nm = n + m;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  float* ABs = reinterpret_cast<float*>(smem);   // n x nm
+  float* P = ABs + n * nm;                       // n x n
+  float* AtP = P + n * n;                        // n x n  (later S)
+  float* T1 = AtP + n * n;                       // n x n
+  float* BtP = T1 + n * n;                       // m x n
+  float* Hm = BtP + m * n;                       // m x n
+  float* HGK = Hm + m * n;                       // m x n
+  float* Kk = HGK + m * n;                       // m x (n+1)
+  float* G = Kk + m * (n + 1);                   // m x m
+  float* Lc = G + m * m;                         // m x m
+  float* pv = Lc + m * m;                        // n
+  float* lam = pv + n;                           // n
+  float* dv = lam + n;                           // n
+  float* qv = dv + n;                            // n
+  float* uv = qv + n;                            // m
+  float* rv = uv + m;                            // m
+  float* hv = rv + m;                            // m
+  float* tv = hv + m;                            // n scratch
+
+  const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]);
+  const float al = GMPC_ALPHA;
+  const float delta = a.mode == 0 ? 1e-8f : 0.f;
+
+  for (int e = lane; e < n * n; e += 64) P[e] = a.QT[(size_t)b * n * n + e];
+  for (int i = lane; i < n; i += 64) {
+    const float q = a.qT[(size_t)b * n + i];
+    pv[i] = a.mode == 0 ? q : 0.f;
+    lam[i] = q;
+    if (a.mode == 0 && a.adj) a.adj[((size_t)b * (T + 1) + T) * n + i] = q;
+  }
+  float gn2 = 0.f;
+  __syncthreads();
+
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t bt = (size_t)b * T + t;
+    for (int e = lane; e < n * nm; e += 64) ABs[e] = a.AB[bt * n * nm + e];
+    for (int i = lane; i < n; i += 64)
+      dv[i] = a.X[((size_t)b * (T + 1) + t) * n + i] - a.goal[((size_t)b * (T + 1) + t) * n + i];
+    for (int j = lane; j < m; j += 64) uv[j] = a.U[bt * m + j];
+    __syncthreads();
+    float dd = 0.f, uu = 0.f;
+    for (int i = 0; i < n; ++i) dd = fmaf(dv[i], dv[i], dd);
+    for (int j = 0; j < m; ++j) uu = fmaf(uv[j], uv[j], uu);
+    const float s = sqrtf(dd + al * al), su = sqrtf(uu + al * al);
+    const float is = 1.f / s, is3 = 1.f / (s * s * s), isu = 1.f / su, isu3 = 1.f / (su * su * su);
+    // q_t, r_t ; adjoint / gradient (iLQR) ; linear terms
+    for (int i = lane; i < n; i += 64) qv[i] = w1 * dv[i] / s;
+    for (int j = lane; j < m; j += 64) rv[j] = w0 * uv[j] / su;
+    __syncthreads();
+    if (a.mode == 0) {
+      // g_t = r_t + B^T lam ; lam_t = q_t + A^T lam
+      for (int j = lane; j < m; j += 64) {
+        float g = 0.f;
+        for (int i = 0; i < n; ++i) g = fmaf(ABs[i * nm + n + j], lam[i], g);
+        g = rv[j] + g;
+        gn2 = fmaf(g, g, gn2);
+        if (a.grad) a.grad[bt * m + j] = g;
+      }
+      for (int c = lane; c < n; c += 64) {
+        float v = 0.f;
+        for (int i = 0; i < n; ++i) v = fmaf(ABs[i * nm + c], lam[i], v);
+        tv[c] = qv[c] + v;
+      }
+      __syncthreads();
+      for (int c = lane; c < n; c += 64) {
+        lam[c] = tv[c];
+        if (a.adj) a.adj[((size_t)b * (T + 1) + t) * n + c] = tv[c];
+      }
+    }
+    // AtP = A^T P ; BtP = B^T P
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      float v = 0.f;
+      for (int k = 0; k < n; ++k) v = fmaf(ABs[k * nm + i], P[k * n + j], v);
+      AtP[e] = v;
+    }
+    for (int e = lane; e < m * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      float v = 0.f;
+      for (int k = 0; k < n; ++k) v = fmaf(ABs[k * nm + n + i], P[k * n + j], v);
+      BtP[e] = v;
+    }
+    __syncthreads();
+    // T1 = AtP A ; Hm = BtP A (+ M^T = 0) ; G = sym(R + BtP B) ; h = r + B^T p
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      float v = 0.f;
+      for (int k = 0; k < n; ++k) v = fmaf(AtP[i * n + k], ABs[k * nm + j], v);
+      T1[e] = v;
+    }
+    for (int e = lane; e < m * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      float v = 0.f;
+      for (int k = 0; k < n; ++k) v = fmaf(BtP[i * n + k], ABs[k * nm + j], v);
+      Hm[e] = v;
+    }
+    for (int e = lane; e < m * m; e += 64) {
+      const int i = e / m, j = e - i * m;
+      float v = 0.f;
+      for (int k = 0; k < n; ++k) v = fmaf(BtP[i * n + k], ABs[k * nm + n + j], v);
+      const float Rij = w0 * ((i == j ? isu : 0.f) - uv[i] * uv[j] * isu3);
+      Lc[e] = Rij + v;  // unsymmetrised, staged in Lc
+    }
+    for (int j = lane; j < m; j += 64) {
+      float v = 0.f;
+      for (int i = 0; i < n; ++i) v = fmaf(ABs[i * nm + n + j], pv[i], v);
+      hv[j] = (a.mode == 0 ? rv[j] : -a.Bvec[bt * m + j]) + v;
+    }
+    __syncthreads();
+    for (int e = lane; e < m * m; e += 64) {
+      const int i = e / m, j = e - i * m;
+      G[e] = (Lc[e] + Lc[j * m + i]) * 0.5f;
+    }
+    __syncthreads();
+    // solve (G + delta I) [K k] = -[H h]
+    if (a.mode == 0) {
+      // Cholesky (NaN on a non-positive pivot, like jax cho_factor)
+      if (lane == 0) {
+        for (int j = 0; j < m; ++j) {
+          float sdiag = G[j * m + j] + delta;
+          for (int k = 0; k < j; ++k) sdiag -= Lc[j * m + k] * Lc[j * m + k];
+          const float d = sqrtf(sdiag);
+          Lc[j * m + j] = d;
+          for (int i = j + 1; i < m; ++i) {
+            float v = G[i * m + j];
+            for (int k = 0; k < j; ++k) v -= Lc[i * m + k] * Lc[j * m + k];
+            Lc[i * m + j] = v / d;
+          }
+        }
+      }
+      __syncthreads();
+      for (int c = lane; c <= n; c += 64) {
+        // column c of the right-hand side: H[:,c] for c<n, h for c==n
+        for (int i = 0; i < m; ++i) {
+          float v = c < n ? Hm[i * n + c] : hv[i];
+          for (int k = 0; k < i; ++k) v -= Lc[i * m + k] * Kk[k * (n + 1) + c];
+          Kk[i * (n + 1) + c] = v / Lc[i * m + i];
+        }
+        for (int i = m - 1; i >= 0; --i) {
+          float v = Kk[i * (n + 1) + c];
+          for (int k = i + 1; k < m; ++k) v -= Lc[k * m + i] * Kk[k * (n + 1) + c];
+          Kk[i * (n + 1) + c] = v / Lc[i * m + i];
+        }
+        for (int i = 0; i < m; ++i) Kk[i * (n + 1) + c] = -Kk[i * (n + 1) + c];
+      }
+    } else {
+      // Gaussian elimination with partial pivoting (jax.scipy.linalg.solve), serial on lane 0
+      if (lane == 0) {
+        for (int e = 0; e < m * m; ++e) Lc[e] = G[e];
+        for (int i = 0; i < m; ++i) {
+          for (int c = 0; c < n; ++c) Kk[i * (n + 1) + c] = Hm[i * n + c];
+          Kk[i * (n + 1) + n] = hv[i];
+        }
+        for (int j = 0; j < m; ++j) {
+          int piv = j;
+          float best = fabsf(Lc[j * m + j]);
+          for (int i = j + 1; i < m; ++i)
+            if (fabsf(Lc[i * m + j]) > best) { best = fabsf(Lc[i * m + j]); piv = i; }
+          if (piv != j) {
+            for (int c = 0; c < m; ++c) { const float t_ = Lc[j * m + c]; Lc[j * m + c] = Lc[piv * m + c]; Lc[piv * m + c] = t_; }
+            for (int c = 0; c <= n; ++c) { const float t_ = Kk[j * (n + 1) + c]; Kk[j * (n + 1) + c] = Kk[piv * (n + 1) + c]; Kk[piv * (n + 1) + c] = t_; }
+          }
+          const float d = Lc[j * m + j];
+          for (int i = j + 1; i < m; ++i) {
+            const float f = Lc[i * m + j] / d;
+            for (int c = j; c < m; ++c) Lc[i * m + c] -= f * Lc[j * m + c];
+            for (int c = 0; c <= n; ++c) Kk[i * (n + 1) + c] -= f * Kk[j * (n + 1) + c];
+          }
+        }
+      }
+      __syncthreads();
+      for (int c = lane; c <= n; c += 64) {
+        for (int i = m - 1; i >= 0; --i) {
+          float v = Kk[i * (n + 1) + c];
+          for (int k = i + 1; k < m; ++k) v -= Lc[i * m + k] * Kk[k * (n + 1) + c];
+          Kk[i * (n + 1) + c] = v / Lc[i * m + i];
+        }
+        for (int i = 0; i < m; ++i) Kk[i * (n + 1) + c] = -Kk[i * (n + 1) + c];
+      }
+    }
+    __syncthreads();
+    // outputs K_t, k_t ; HGK = H + G K
+    if (a.K)
+      for (int e = lane; e < m * n; e += 64) {
+        const int i = e / n, j = e - i * n;
+        a.K[bt * m * n + e] = Kk[i * (n + 1) + j];
+      }
+    if (a.k)
+      for (int j = lane; j < m; j += 64) a.k[bt * m + j] = Kk[j * (n + 1) + n];
+    for (int e = lane; e < m * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      float v = 0.f;
+      for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], Kk[k * (n + 1) + j], v);
+      HGK[e] = Hm[e] + v;
+    }
+    __syncthreads();
+    // S = Q + sym(T1) + HGK^T K + K^T H   (staged in AtP), P = sym(S)
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const float Qij = w1 * ((i == j ? is : 0.f) - dv[i] * dv[j] * is3);
+      float v1 = 0.f, v2 = 0.f;
+      for (int k = 0; k < m; ++k) {
+        v1 = fmaf(HGK[k * n + i], Kk[k * (n + 1) + j], v1);
+        v2 = fmaf(Kk[k * (n + 1) + i], Hm[k * n + j], v2);
+      }
+      AtP[e] = ((Qij + (T1[e] + T1[j * n + i]) * 0.5f) + v1) + v2;
+    }
+    // p = q + A^T p + HGK^T k + K^T h
+    for (int i = lane; i < n; i += 64) {
+      float v = 0.f, v1 = 0.f, v2 = 0.f;
+      for (int k = 0; k < n; ++k) v = fmaf(ABs[k * nm + i], pv[k], v);
+      for (int k = 0; k < m; ++k) {
+        v1 = fmaf(HGK[k * n + i], Kk[k * (n + 1) + n], v1);
+        v2 = fmaf(Kk[k * (n + 1) + i], hv[k], v2);
+      }
+      tv[i] = (((a.mode == 0 ? qv[i] : 0.f) + v) + v1) + v2;
+    }
+    __syncthreads();
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      P[e] = (AtP[e] + AtP[j * n + i]) * 0.5f;
+    }
+    for (int i = lane; i < n; i += 64) pv[i] = tv[i];
+    __syncthreads();
+  }
+
+  if (a.mode == 0) {
+    if (a.cont != nullptr) {
+      gn2 = wave_sum(gn2);
+      float un2 = 0.f;
+      for (int e = lane; e < T * m; e += 64) {
+        const float u = a.U[(size_t)b * T * m + e];
+        un2 = fmaf(u, u, un2);
+      }
+      un2 = wave_sum(un2);
+      if (lane == 0) {
+        float gn = sqrtf(gn2);
+        if (isnan(gn)) gn = INFINITY;
+        const float aobj = fabsf(a.obj[b]) + 1.0f;
+        const float un = sqrtf(un2) + 1.0f;
+        const bool progressing = (a.obj_step[b] > a.opts.obj_step_threshold * aobj) &&
+                                 (a.U_step[b] > a.opts.inputs_step_threshold * un);
+        const bool potential = (gn > a.opts.grad_norm_threshold) &&
+                               (gn > a.opts.relative_grad_norm_threshold * aobj);
+        const bool go = (a.iters[b] < a.opts.maxiter) && progressing && potential &&
+                        (a.alpha[b] > a.opts.alpha_min);
+        a.cont[b] = go ? 1 : 0;
+      }
+    }
+    return;
+  }
+  // mode 1: forward tangent roll  dU_t = k_t + K_t dX_t ; dX_{t+1} = A dX_t + B dU_t
+  // (gains were written to a.K / a.k by the sweep above; the caller passes scratch buffers)
+  for (int i = lane; i < n; i += 64) { pv[i] = 0.f; a.dX[(size_t)b * (T + 1) * n + i] = 0.f; }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const size_t bt = (size_t)b * T + t;
+    for (int e = lane; e < n * nm; e += 64) ABs[e] = a.AB[bt * n * nm + e];
+    for (int j = lane; j < m; j += 64) {
+      float v = a.k[bt * m + j];
+      for (int i = 0; i < n; ++i) v = fmaf(a.K[bt * m * n + j * n + i], pv[i], v);
+      uv[j] = v;
+      a.Hout[bt * m + j] = v;
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+      float v = 0.f;
+      for (int k = 0; k < n; ++k) v = fmaf(ABs[i * nm + k], pv[k], v);
+      for (int k = 0; k < m; ++k) v = fmaf(ABs[i * nm + n + k], uv[k], v);
+      tv[i] = v;
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) {
+      pv[i] = tv[i];
+      a.dX[((size_t)b * (T + 1) + t + 1) * n + i] = tv[i];
+    }
+    __syncthreads();
+  }
+}
+
+size_t gmpc_riccati_lds_bytes(int n, int m) {
+  const size_t f = (size_t)n * (n + m) + 3 * (size_t)n * n + 3 * (size_t)m * n + (size_t)m * (n + 1) +
+                   2 * (size_t)m * m + 5 * (size_t)n + 3 * (size_t)m;
+  return f * sizeof(float);
+}
+
+// Host-side launchers ---------------------------------------------------------------------------
+template <int R4>
+static void launch_lin(int B, int T, int n, int m, int SP, const MlpDesc& dyn, const uint32_t* masks,
+                       const int* active, float* AB, hipStream_t s) {
+  const int ngroups = (B * T + SP - 1) / SP;
+  const int grid = ngroups < 4096 ? ngroups : 4096;
+  const size_t lds = 2 * (size_t)GMPC_THREADS * R4 * sizeof(float4);
+  hipLaunchKernelGGL(k_linearize<R4>, dim3(grid), dim3(GMPC_THREADS), lds, s, B, T, n, m, SP, dyn,
+                     masks, active, AB);
+}
+
+int gmpc_launch_linearize(int B, int T, int n, int m, const MlpDesc& dyn, const uint32_t* masks,
+                          const int* active, float* AB, hipStream_t s) {
+  // rows per pass: as many whole samples as fit in 24 rows, at least one sample
+  int SP = 24 / n;
+  if (SP < 1) SP = 1;
+  const int R4 = (SP * n + 3) / 4;
+  switch (R4) {
+#define GMPC_LIN_CASE(q) case q: launch_lin<q>(B, T, n, m, SP, dyn, masks, active, AB, s); return 0;
+    GMPC_LIN_CASE(1) GMPC_LIN_CASE(2) GMPC_LIN_CASE(3) GMPC_LIN_CASE(4) GMPC_LIN_CASE(5)
+    GMPC_LIN_CASE(6) GMPC_LIN_CASE(7) GMPC_LIN_CASE(8) GMPC_LIN_CASE(9) GMPC_LIN_CASE(10)
+    GMPC_LIN_CASE(11) GMPC_LIN_CASE(12) GMPC_LIN_CASE(13) GMPC_LIN_CASE(14) GMPC_LIN_CASE(15)
+    GMPC_LIN_CASE(16)
+#undef GMPC_LIN_CASE
+    default: return -1;
+  }
+}
+
+int gmpc_launch_terminal(int B, int T, int n, const MlpDesc& cm, const float* mpc_w, const float* X,
+                         const int* active, float* QT, float* qT, hipStream_t s) {
+  const int fo = cm.dims[cm.L];
+  const int R4 = (fo + 3) / 4;
+  size_t lds;
+  switch (R4) {
+#define GMPC_TERM_CASE(q)                                                                          \
+  case q:                                                                                          \
+    lds = 2 * (size_t)GMPC_THREADS * q * sizeof(float4) +                                          \
+          (GMPC_MAX_LAYERS * GMPC_THREADS + 64) * sizeof(float);                                   \
+    hipLaunchKernelGGL(k_terminal<q>, dim3(B), dim3(GMPC_THREADS), lds, s, B, T, n, cm, mpc_w, X,  \
+                       active, QT, qT);                                                            \
+    return 0;
+    GMPC_TERM_CASE(1) GMPC_TERM_CASE(2) GMPC_TERM_CASE(3) GMPC_TERM_CASE(4) GMPC_TERM_CASE(5)
+    GMPC_TERM_CASE(6) GMPC_TERM_CASE(7) GMPC_TERM_CASE(8)
+#undef GMPC_TERM_CASE
+    default: return -1;
+  }
+}
+
+void gmpc_launch_riccati(const RiccatiArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_riccati, dim3(a.B), dim3(64), gmpc_riccati_lds_bytes(a.n, a.m), s, a);
+}

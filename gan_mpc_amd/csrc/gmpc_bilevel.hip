@@ -1,0 +1,197 @@
+// Upper-level ("bilevel") gradient pieces that are not the Riccati sweep itself.
+//
+// Reference arithmetic: policy/optimizers.py:61-73,78-105 (loss_grad_wrt_control, the dense
+// Hessian solve -- here the equivalent structured solve, see k_riccati mode 1 -- and cost_vjp),
+// norm/l2_policy.py:12-18.
+#include "gmpc_device.h"
+
+// L2 loss  sum_dims mean_t (x - x*)^2  and its gradient wrt X.
+__global__ __launch_bounds__(GMPC_THREADS) void k_l2loss(int B, int T, int n, const float* X,
+                                                         const float* desired, float* loss,
+                                                         float* lx) {
+  __shared__ float sh[GMPC_THREADS];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cnt = (T + 1) * n;
+  const float inv = 1.0f / (float)(T + 1);
+  float s = 0.f;
+  for (int e = tid; e < cnt; e += blockDim.x) {
+    const float d = X[(size_t)b * cnt + e] - desired[(size_t)b * cnt + e];
+    s = fmaf(d, d, s);
+    lx[(size_t)b * cnt + e] = 2.f * d * inv;
+  }
+  sh[tid] = s;
+  __syncthreads();
+  for (int o = GMPC_THREADS / 2; o > 0; o >>= 1) {
+    if (tid < o) sh[tid] += sh[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) loss[b] = sh[0] * inv;
+}
+
+// a8: Bvec_t = B_t^T mu_{t+1}, mu_T = lx_T, mu_t = lx_t + A_t^T mu_{t+1}.  One wave per trajectory.
+__global__ __launch_bounds__(64) void k_bvec(int B, int T, int n, int m, const float* AB,
+                                             const float* lx, float* Bvec) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ABs = reinterpret_cast<float*>(smem);
+  float* mu = ABs + n * (n + m);
+  float* tv = mu + n;
+  const int lane = threadIdx.x, b = blockIdx.x, nm = n + m;
+  for (int i = lane; i < n; i += 64) mu[i] = lx[((size_t)b * (T + 1) + T) * n + i];
+  __syncthreads();
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t bt = (size_t)b * T + t;
+    for (int e = lane; e < n * nm; e += 64) ABs[e] = AB[bt * n * nm + e];
+    __syncthreads();
+    for (int j = lane; j < m; j += 64) {
+      float v = 0.f;
+      for (int i = 0; i < n; ++i) v = fmaf(ABs[i * nm + n + j], mu[i], v);
+      Bvec[bt * m + j] = v;
+    }
+    for (int c = lane; c < n; c += 64) {
+      float v = 0.f;
+      for (int i = 0; i < n; ++i) v = fmaf(ABs[i * nm + c], mu[i], v);
+      tv[c] = lx[((size_t)b * (T + 1) + t) * n + c] + v;
+    }
+    __syncthreads();
+    for (int c = lane; c < n; c += 64) mu[c] = tv[c];
+    __syncthreads();
+  }
+}
+
+// a11: per trajectory, the theta-gradient of  H . grad_U J(U; theta)  =  directional derivative of the
+// total cost along (dX, H).  mpc_w part is finished here; for the cost MLP the kernel emits the layer
+// inputs (primal row b, tangent row B+b) and the matching adjoints, and the weight gradients are the
+// row-sum GEMMs  gW_l = sum_rows cact_l^T cdel_l,  gb_l = sum of the primal adjoint rows.
+__global__ __launch_bounds__(GMPC_THREADS) void k_costvjp(int B, int T, int n, int m, MlpDesc cm,
+                                                          const float* mpc_w, float sign,
+                                                          const float* X, const float* U,
+                                                          const float* goal, const float* Hc,
+                                                          const float* dX, float* gmpc /*[B][3]*/,
+                                                          float* cact, float* cdel, int stride) {
+  __shared__ float4 bufA[GMPC_THREADS];
+  __shared__ float4 bufB[GMPC_THREADS];
+  __shared__ float zpos[GMPC_MAX_LAYERS][GMPC_THREADS];
+  __shared__ float red[2][GMPC_THREADS / 64];
+  __shared__ float yv[2][64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x;
+  const float al = GMPC_ALPHA;
+  const float r0 = mpc_w[0], r1 = mpc_w[1], r2 = mpc_w[2];
+  const float w0 = sigmoidf_(r0), w1 = sigmoidf_(r1), w2 = sigmoidf_(r2);
+  // ---- stage sums: each wave takes every 4th step
+  float du_dir = 0.f, dx_dir = 0.f;
+  for (int t = wave; t < T; t += GMPC_THREADS / 64) {
+    float uu = 0.f, uh = 0.f, dd = 0.f, dxd = 0.f;
+    for (int j = lane; j < m; j += 64) {
+      const float u = U[((size_t)b * T + t) * m + j];
+      uu = fmaf(u, u, uu);
+      uh = fmaf(u, Hc[((size_t)b * T + t) * m + j], uh);
+    }
+    for (int i = lane; i < n; i += 64) {
+      const size_t xi = ((size_t)b * (T + 1) + t) * n + i;
+      const float d = X[xi] - goal[xi];
+      dd = fmaf(d, d, dd);
+      dxd = fmaf(d, dX[xi], dxd);
+    }
+    uu = wave_sum(uu); uh = wave_sum(uh); dd = wave_sum(dd); dxd = wave_sum(dxd);
+    du_dir += uh / sqrtf(uu + al * al);
+    dx_dir += dxd / sqrtf(dd + al * al);
+  }
+  if (lane == 0) { red[0][wave] = du_dir; red[1][wave] = dx_dir; }
+  // ---- terminal: primal (.x) and tangent (.y) streams through the cost MLP
+  const int Lc = cm.L - 1;
+  const int fo = cm.dims[Lc + 1];
+  float4* in = bufA;
+  float4* out = bufB;
+  if (tid < n) {
+    const size_t xi = ((size_t)b * (T + 1) + T) * n + tid;
+    in[tid] = make_float4(X[xi], dX[xi], 0.f, 0.f);
+    cact[(size_t)b * stride + tid] = X[xi];
+    cact[(size_t)(B + b) * stride + tid] = dX[xi];
+  }
+  __syncthreads();
+  int aoff = n;
+  for (int l = 0; l < Lc; ++l) {
+    const int K = cm.dims[l], N = cm.dims[l + 1];
+    float4 acc[1] = {make_float4(tid < N ? cm.b[l][tid] : 0.f, 0.f, 0.f, 0.f)};
+    dense_rows<1>(cm.W[l], K, N, tid, in, acc);
+    if (tid < N) {
+      const float mk = acc[0].x > 0.f ? 1.f : 0.f;
+      zpos[l][tid] = mk;
+      const float pa = acc[0].x * mk, ta = acc[0].y * mk;
+      out[tid] = make_float4(pa, ta, 0.f, 0.f);
+      cact[(size_t)b * stride + aoff + tid] = pa;
+      cact[(size_t)(B + b) * stride + aoff + tid] = ta;
+    }
+    aoff += N;
+    __syncthreads();
+    float4* tmp = in; in = out; out = tmp;
+  }
+  if (tid < fo) {
+    const int K = cm.dims[Lc];
+    float y = cm.b[Lc][tid], yd = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float w = cm.W[Lc][(size_t)k * fo + tid];
+      y = fmaf(w, in[k].x, y);
+      yd = fmaf(w, in[k].y, yd);
+    }
+    yv[0][tid] = y;
+    yv[1][tid] = yd;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float td = 0.f;
+    for (int r = 0; r < fo; ++r) td = fmaf(yv[0][r], yv[1][r], td);
+    td *= 2.f;
+    const float du = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float dx = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    gmpc[(size_t)b * 3 + 0] = sign * (w0 * (1.f - w0)) * du;
+    gmpc[(size_t)b * 3 + 1] = sign * (w1 * (1.f - w1)) * dx;
+    gmpc[(size_t)b * 3 + 2] = sign * (w2 * (1.f - w2)) * td;
+  }
+  // ---- backward: adjoints of (y, ydot) are (ydot, y) * 2 w2 * sign
+  const float scale = 2.f * w2 * sign;
+  int doff = 0;
+  for (int l = 0; l <= Lc; ++l) doff += cm.dims[l + 1];
+  doff -= fo;
+  if (tid < fo) {
+    const float yb = yv[1][tid] * scale, ydb = yv[0][tid] * scale;
+    out[tid] = make_float4(yb, ydb, 0.f, 0.f);
+    cdel[(size_t)b * stride + doff + tid] = yb;
+    cdel[(size_t)(B + b) * stride + doff + tid] = ydb;
+  }
+  __syncthreads();
+  for (int l = Lc; l >= 1; --l) {
+    const int K = cm.dims[l + 1], N = cm.dims[l];
+    float4 acc[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+    dense_rows<1>(cm.WT[l], K, N, tid, out, acc);
+    doff -= N;
+    if (tid < N) {
+      const float mk = zpos[l - 1][tid];
+      const float zb = acc[0].x * mk, zdb = acc[0].y * mk;
+      in[tid] = make_float4(zb, zdb, 0.f, 0.f);
+      cdel[(size_t)b * stride + doff + tid] = zb;
+      cdel[(size_t)(B + b) * stride + doff + tid] = zdb;
+    }
+    __syncthreads();
+    float4* tmp = in; in = out; out = tmp;
+  }
+}
+
+// Host-side launchers ---------------------------------------------------------------------------
+void gmpc_launch_l2loss(int B, int T, int n, const float* X, const float* desired, float* loss,
+                        float* lx, hipStream_t s) {
+  hipLaunchKernelGGL(k_l2loss, dim3(B), dim3(GMPC_THREADS), 0, s, B, T, n, X, desired, loss, lx);
+}
+void gmpc_launch_bvec(int B, int T, int n, int m, const float* AB, const float* lx, float* Bvec,
+                      hipStream_t s) {
+  const size_t lds = ((size_t)n * (n + m) + 2 * n) * sizeof(float);
+  hipLaunchKernelGGL(k_bvec, dim3(B), dim3(64), lds, s, B, T, n, m, AB, lx, Bvec);
+}
+void gmpc_launch_costvjp(int B, int T, int n, int m, const MlpDesc& cm, const float* mpc_w,
+                         float sign, const float* X, const float* U, const float* goal,
+                         const float* Hc, const float* dX, float* gmpc, float* cact, float* cdel,
+                         int stride, hipStream_t s) {
+  hipLaunchKernelGGL(k_costvjp, dim3(B), dim3(GMPC_THREADS), 0, s, B, T, n, m, cm, mpc_w, sign, X, U,
+                     goal, Hc, dX, gmpc, cact, cdel, stride);
+}

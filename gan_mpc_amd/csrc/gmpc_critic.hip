@@ -1,0 +1,466 @@
+// Critic (discriminator) kernels: LSTM(F) over the T+1 rows of each sequence, final h -> relu head ->
+// score; BCE / generator loss; BPTT; weight gradients as row-sum GEMMs; clip + Adam.
+//
+// Reference arithmetic: critic/nn.py:28-42 (flax OptimizedLSTMCell scanned over the sequence, zero
+// carry, gate order i,f,g,o), gan/js_policy.py:41-68 (losses), gan/runner.py:51-63 (optimiser).
+//
+// Layout: a workgroup of 256 threads owns SB = 4*R4 sequences for the whole sweep.  Thread j
+// produces gate pre-activation j (4F = 256 with the reference's F = 64) for all SB sequences from
+// the concatenated kernel Wcat = [Wx; Wh] ((n+F) x 4F, exactly the flat critic layout), the cell
+// update runs as thread (unit, wave).  Saved per (sequence, step): activated gates, c_t, h_{t-1}.
+#include "gmpc_device.h"
+
+
+template <int R4>
+__global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd, const float* xseq,
+                                                           float* gates, float* cs, float* hp,
+                                                           float* hT) {
+  constexpr int SB = 4 * R4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* act = reinterpret_cast<float4*>(smem);            // [(n+F)][R4]
+  float4* gbuf = act + (cd.n + cd.F) * R4;                  // [4F][R4]
+  const int tid = threadIdx.x;
+  const int n = cd.n, F = cd.F, T1 = cd.T1, G4 = 4 * F, K = n + F;
+  const int s0 = blockIdx.x * SB;
+  const int u = tid % F, grp = tid / F;       // cell-update role (F*4 == blockDim)
+  constexpr int SPT = SB / 4;                 // sequences per thread in the cell update
+  float c[SPT];
+#pragma unroll
+  for (int e = 0; e < SPT; ++e) c[e] = 0.f;
+  float* actf = reinterpret_cast<float*>(act);
+  float* gbf = reinterpret_cast<float*>(gbuf);
+  for (int e = tid; e < F * SB; e += blockDim.x) actf[n * SB + e] = 0.f;   // h_{-1} = 0
+  const float bj = tid < G4 ? cd.b[tid] : 0.f;
+  for (int t = 0; t < T1; ++t) {
+    for (int e = tid; e < n * SB; e += blockDim.x) {
+      const int sb = e / n, i = e - sb * n;
+      const int s = min(s0 + sb, Bc - 1);
+      actf[i * SB + sb] = xseq[((size_t)s * T1 + t) * n + i];
+    }
+    __syncthreads();
+    // save h_{t-1}
+    for (int e = tid; e < F * SB; e += blockDim.x) {
+      const int sb = e / F, k = e - sb * F;
+      if (s0 + sb < Bc) hp[((size_t)(s0 + sb) * T1 + t) * F + k] = actf[(n + k) * SB + sb];
+    }
+    float4 acc[R4];
+#pragma unroll
+    for (int q = 0; q < R4; ++q) acc[q] = make_float4(bj, bj, bj, bj);
+    dense_rows<R4>(cd.Wcat, K, G4, tid, act, acc);
+    if (tid < G4) {
+      const bool is_g = (tid >= 2 * F) && (tid < 3 * F);
+#pragma unroll
+      for (int q = 0; q < R4; ++q) {
+        float4 v = acc[q];
+        if (is_g) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+        else { v.x = sigmoidf_(v.x); v.y = sigmoidf_(v.y); v.z = sigmoidf_(v.z); v.w = sigmoidf_(v.w); }
+        gbuf[tid * R4 + q] = v;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int sb = q * 4 + cc;
+          if (s0 + sb < Bc) gates[((size_t)(s0 + sb) * T1 + t) * G4 + tid] = f4get(v, cc);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < SPT; ++e) {
+      const int sb = grp * SPT + e;
+      const float ig = gbf[(0 * F + u) * SB + sb], fg = gbf[(1 * F + u) * SB + sb];
+      const float gg = gbf[(2 * F + u) * SB + sb], og = gbf[(3 * F + u) * SB + sb];
+      c[e] = fg * c[e] + ig * gg;
+      const float h = og * tanhf(c[e]);
+      actf[(n + u) * SB + sb] = h;
+      if (s0 + sb < Bc) {
+        cs[((size_t)(s0 + sb) * T1 + t) * F + u] = c[e];
+        if (t == T1 - 1) hT[(size_t)(s0 + sb) * F + u] = h;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Head forward + loss + head backward, per sequence.  loss_kind 0: BCE with labels (js_policy.py:
+// 41-46) -> dscore = -(1-p) or p; 1: generator loss (js_policy.py:60-68) -> dscore = -1;
+// 2: score only, dscore = +1 (plain VJP of the score).  Stores per-layer inputs `acts` and deltas
+// `dels` for the weight-gradient GEMMs, dhT for the BPTT, score and per-sequence loss.
+template <int R4>
+__global__ __launch_bounds__(GMPC_THREADS) void k_head(int Bc, CriticDesc cd, int loss_kind,
+                                                       const float* hT, const float* label,
+                                                       float* score, float* loss, float* acts,
+                                                       float* dels, float* dhT, int act_stride) {
+  constexpr int SB = 4 * R4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* bufA = reinterpret_cast<float4*>(smem);
+  float4* bufB = bufA + GMPC_THREADS * R4;
+  float4* part = bufB + GMPC_THREADS * R4;
+  float* zpos = reinterpret_cast<float*>(part + GMPC_THREADS * R4);  // [L][256][SB]
+  const int tid = threadIdx.x;
+  const int s0 = blockIdx.x * SB;
+  const MlpDesc& hd = cd.head;
+  const int L = hd.L, F = cd.F;
+  float* af = reinterpret_cast<float*>(bufA);
+  for (int e = tid; e < F * SB; e += blockDim.x) {
+    const int sb = e / F, k = e - sb * F;
+    const int s = min(s0 + sb, Bc - 1);
+    const float v = hT[(size_t)s * F + k];
+    af[k * SB + sb] = v;
+    if (s0 + sb < Bc) acts[(size_t)(s0 + sb) * act_stride + k] = v;
+  }
+  __syncthreads();
+  float4* in = bufA;
+  float4* out = bufB;
+  int aoff = F;
+  for (int l = 0; l < L - 1; ++l) {
+    const int K = hd.dims[l], N = hd.dims[l + 1];
+    const float bj = tid < N ? hd.b[l][tid] : 0.f;
+    float4 acc[R4];
+#pragma unroll
+    for (int q = 0; q < R4; ++q) acc[q] = make_float4(bj, bj, bj, bj);
+    dense_rows<R4>(hd.W[l], K, N, tid, in, acc);
+    if (tid < N) {
+#pragma unroll
+      for (int q = 0; q < R4; ++q) {
+        float4 v = acc[q];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int sb = q * 4 + cc;
+          const float z = f4get(v, cc);
+          zpos[(l * GMPC_THREADS + tid) * SB + sb] = z > 0.f ? 1.f : 0.f;
+          const float r = fmaxf(z, 0.f);
+          f4set(v, cc, r);
+          if (s0 + sb < Bc) acts[(size_t)(s0 + sb) * act_stride + aoff + tid] = r;
+        }
+        out[tid * R4 + q] = v;
+      }
+    }
+    aoff += N;
+    __syncthreads();
+    float4* tmp = in; in = out; out = tmp;
+  }
+  // last layer: one output
+  dense_small<R4>(hd.W[L - 1], hd.dims[L - 1], 1, in, part);
+  // loss and dscore (thread sb)
+  float* dsc = reinterpret_cast<float*>(out);   // [1][SB] delta of the last layer
+  if (tid < SB) {
+    const int sb = tid;
+    const float sc = reinterpret_cast<float*>(part)[sb] + hd.b[L - 1][0];
+    float ds, ls;
+    if (loss_kind == 0) {
+      const float p = sigmoidf_(sc);
+      const int s = min(s0 + sb, Bc - 1);
+      const bool pos = label[s] > 0.f;
+      ls = -logf(pos ? p : 1.f - p);
+      ds = pos ? -(1.f - p) : p;
+    } else if (loss_kind == 1) {
+      const float p = sigmoidf_(sc);
+      ls = -logf(p) + logf(1.f - p);
+      ds = -1.f;
+    } else {
+      ls = 0.f;
+      ds = 1.f;
+    }
+    dsc[sb] = ds;
+    if (s0 + sb < Bc) {
+      score[s0 + sb] = sc;
+      loss[s0 + sb] = ls;
+    }
+  }
+  __syncthreads();
+  // backward through the head; `out` holds delta of layer l as [N_l][SB]
+  int doff = 0;
+  for (int l = 0; l < L; ++l) doff += hd.dims[l + 1];
+  for (int l = L - 1; l >= 0; --l) {
+    const int K = hd.dims[l + 1], N = hd.dims[l];
+    doff -= K;
+    const float* df = reinterpret_cast<const float*>(out);
+    for (int e = tid; e < K * SB; e += blockDim.x) {
+      const int j = e / SB, sb = e - j * SB;
+      if (s0 + sb < Bc) dels[(size_t)(s0 + sb) * act_stride + doff + j] = df[j * SB + sb];
+    }
+    float4 acc[R4];
+#pragma unroll
+    for (int q = 0; q < R4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dense_rows<R4>(hd.WT[l], K, N, tid, out, acc);
+    __syncthreads();
+    if (tid < N) {
+#pragma unroll
+      for (int q = 0; q < R4; ++q) {
+        float4 v = acc[q];
+        if (l > 0) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+            f4set(v, cc, f4get(v, cc) * zpos[((l - 1) * GMPC_THREADS + tid) * SB + q * 4 + cc]);
+        }
+        in[tid * R4 + q] = v;
+      }
+    }
+    __syncthreads();
+    float4* tmp = in; in = out; out = tmp;
+  }
+  const float* df = reinterpret_cast<const float*>(out);   // d hT as [F][SB]
+  for (int e = tid; e < F * SB; e += blockDim.x) {
+    const int sb = e / F, k = e - sb * F;
+    if (s0 + sb < Bc) dhT[(size_t)(s0 + sb) * F + k] = df[k * SB + sb];
+  }
+}
+
+template <int R4>
+__global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd, const float* gates,
+                                                           const float* cs, const float* dhT,
+                                                           float* dz, float* dxseq) {
+  constexpr int SB = 4 * R4;
+  constexpr int SPT = SB / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* dzb = reinterpret_cast<float4*>(smem);            // [4F][R4]
+  float4* part = dzb + GMPC_THREADS * R4;                   // dense_small scratch / result
+  const int tid = threadIdx.x;
+  const int n = cd.n, F = cd.F, T1 = cd.T1, G4 = 4 * F, K = n + F;
+  const int s0 = blockIdx.x * SB;
+  const int u = tid % F, grp = tid / F;
+  float* dzf = reinterpret_cast<float*>(dzb);
+  float dh[SPT], dc[SPT];
+#pragma unroll
+  for (int e = 0; e < SPT; ++e) {
+    const int s = min(s0 + grp * SPT + e, Bc - 1);
+    dh[e] = dhT[(size_t)s * F + u];
+    dc[e] = 0.f;
+  }
+  for (int t = T1 - 1; t >= 0; --t) {
+#pragma unroll
+    for (int e = 0; e < SPT; ++e) {
+      const int sb = grp * SPT + e;
+      const int s = min(s0 + sb, Bc - 1);
+      const size_t gb = ((size_t)s * T1 + t) * G4;
+      const float ig = gates[gb + u], fg = gates[gb + F + u], gg = gates[gb + 2 * F + u],
+                  og = gates[gb + 3 * F + u];
+      const float ct = cs[((size_t)s * T1 + t) * F + u];
+      const float cprev = t > 0 ? cs[((size_t)s * T1 + t - 1) * F + u] : 0.f;
+      const float tc = tanhf(ct);
+      const float d_o = dh[e] * tc;
+      dc[e] = dc[e] + dh[e] * og * (1.f - tc * tc);
+      const float di = dc[e] * gg, df_ = dc[e] * cprev, dg = dc[e] * ig;
+      const float zi = di * ig * (1.f - ig), zf = df_ * fg * (1.f - fg), zg = dg * (1.f - gg * gg),
+                  zo = d_o * og * (1.f - og);
+      dzf[(0 * F + u) * SB + sb] = zi;
+      dzf[(1 * F + u) * SB + sb] = zf;
+      dzf[(2 * F + u) * SB + sb] = zg;
+      dzf[(3 * F + u) * SB + sb] = zo;
+      if (s0 + sb < Bc && dz != nullptr) {
+        float* d = dz + gb;
+        d[u] = zi; d[F + u] = zf; d[2 * F + u] = zg; d[3 * F + u] = zo;
+      }
+      dc[e] = dc[e] * fg;
+    }
+    __syncthreads();
+    // [dx ; dh_prev][k][sb] = sum_j WcatT[j][k] dz[j][sb]
+    dense_small<R4>(cd.WcatT, G4, K, dzb, part);
+    const float* pf = reinterpret_cast<const float*>(part);
+#pragma unroll
+    for (int e = 0; e < SPT; ++e) dh[e] = pf[(n + u) * SB + grp * SPT + e];
+    if (dxseq != nullptr) {
+      for (int e = tid; e < n * SB; e += blockDim.x) {
+        const int sb = e / n, i = e - sb * n;
+        if (s0 + sb < Bc) dxseq[((size_t)(s0 + sb) * T1 + t) * n + i] = pf[i * SB + sb];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// C[M][N] (+ colsum) partials: Cp[split][M][N] = sum over a row chunk of A[r][:M]^T B[r][:N].
+// 64x64 tile per workgroup, 4x4 micro-tile per thread, 16 rows per LDS stage.
+__global__ __launch_bounds__(GMPC_THREADS) void k_wgrad(int rows, int M, int N, const float* A,
+                                                        int lda, const float* Bm, int ldb,
+                                                        int rows_per_split, float* Cp,
+                                                        float* colsum_p, int cs_rows) {
+  __shared__ float As[16][64 + 4];
+  __shared__ float Bs[16][64 + 4];
+  const int tid = threadIdx.x;
+  const int tm = blockIdx.x * 64, tn = blockIdx.y * 64, sp = blockIdx.z;
+  const int r0 = sp * rows_per_split, r1 = min(rows, r0 + rows_per_split);
+  const int ty = tid / 16, tx = tid % 16;   // micro-tile rows ty*4.., cols tx*4..
+  float acc[4][4] = {};
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = (colsum_p != nullptr) && (blockIdx.x == 0);
+  for (int rb = r0; rb < r1; rb += 16) {
+    for (int e = tid; e < 16 * 64; e += blockDim.x) {
+      const int rr = e / 64, cidx = e % 64;
+      const int r = rb + rr;
+      As[rr][cidx] = (r < r1 && tm + cidx < M) ? A[(size_t)r * lda + tm + cidx] : 0.f;
+      Bs[rr][cidx] = (r < r1 && tn + cidx < N) ? Bm[(size_t)r * ldb + tn + cidx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = As[rr][ty * 4 + i]; bv[i] = Bs[rr][tx * 4 + i]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+      if (do_cs && ty == 0 && rb + rr < cs_rows) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) csum[j] += bv[j];
+      }
+    }
+    __syncthreads();
+  }
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const int mm = tm + ty * 4 + i, nn = tn + tx * 4 + j;
+      if (mm < M && nn < N) Cp[((size_t)sp * M + mm) * N + nn] = acc[i][j];
+    }
+  if (do_cs && ty == 0)
+    for (int j = 0; j < 4; ++j) {
+      const int nn = tn + tx * 4 + j;
+      if (nn < N) colsum_p[(size_t)sp * N + nn] = csum[j];
+    }
+}
+
+// out[e] = sum_sp part[sp][e] in split order (deterministic)
+__global__ void k_reduce_splits(int count, int nsplit, const float* part, float* out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * count + e];
+  out[e] = s;
+}
+
+// Single-block sum of `count` floats (fixed order: thread-strided partials, then tree in LDS).
+__global__ __launch_bounds__(1024) void k_sum(int count, const float* v, float* out, int square) {
+  __shared__ float sh[1024];
+  float s = 0.f;
+  for (int e = threadIdx.x; e < count; e += blockDim.x) {
+    const float x = v[e];
+    s += square ? x * x : x;
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+__global__ void k_transpose(int R, int C, const float* in, float* out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= R * C) return;
+  const int r = e / C, c = e - r * C;
+  out[(size_t)c * R + r] = in[e];
+}
+
+// two-stage sum of squares of (grad * scale): partials per block, then k_sum
+__global__ __launch_bounds__(GMPC_THREADS) void k_sqsum_part(long count, const float* g, float scale,
+                                                             float* part) {
+  __shared__ float sh[GMPC_THREADS];
+  float s = 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+       e += (long)gridDim.x * blockDim.x) {
+    const float x = g[e] * scale;
+    s = fmaf(x, x, s);
+  }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = GMPC_THREADS / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+// optax clip_by_global_norm + adam (gan/runner.py:58): g <- g*scale; if !(norm < max_norm)
+// g <- g / norm * max_norm; m,v update; p += -lr * mhat / (sqrt(vhat) + eps)
+__global__ void k_adam(long count, float* p, const float* g, float* m, float* v, float scale,
+                       const float* sqsum, float max_norm, float lr, float b1, float b2, float eps,
+                       float bc1, float bc2) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= count) return;
+  const float gn = sqrtf(sqsum[0]);
+  float x = g[e] * scale;
+  if (!(gn < max_norm)) x = x / gn * max_norm;
+  const float mn = b1 * m[e] + (1.f - b1) * x;
+  const float vn = b2 * v[e] + (1.f - b2) * x * x;
+  m[e] = mn;
+  v[e] = vn;
+  const float mh = mn / bc1, vh = vn / bc2;
+  p[e] = p[e] + (-lr * mh / (sqrtf(vh) + eps));
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+void gmpc_launch_transpose(int R, int C, const float* in, float* out, hipStream_t s) {
+  const int cnt = R * C;
+  hipLaunchKernelGGL(k_transpose, dim3((cnt + 255) / 256), dim3(256), 0, s, R, C, in, out);
+}
+
+#define GMPC_CR4 2   // 8 sequences per workgroup
+
+void gmpc_launch_lstm_fwd(int Bc, const CriticDesc& cd, const float* xseq, float* gates, float* cs,
+                          float* hp, float* hT, hipStream_t s) {
+  constexpr int R4 = GMPC_CR4;
+  const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
+  const size_t lds = ((size_t)(cd.n + cd.F) + 4 * cd.F) * R4 * sizeof(float4);
+  hipLaunchKernelGGL(k_lstm_fwd<R4>, dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates, cs,
+                     hp, hT);
+}
+
+void gmpc_launch_head(int Bc, const CriticDesc& cd, int loss_kind, const float* hT,
+                      const float* label, float* score, float* loss, float* acts, float* dels,
+                      float* dhT, int act_stride, hipStream_t s) {
+  constexpr int R4 = GMPC_CR4;
+  const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
+  const size_t lds = 3 * (size_t)GMPC_THREADS * R4 * sizeof(float4) +
+                     (size_t)GMPC_MAX_LAYERS * GMPC_THREADS * 4 * R4 * sizeof(float);
+  hipLaunchKernelGGL(k_head<R4>, dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, loss_kind, hT, label,
+                     score, loss, acts, dels, dhT, act_stride);
+}
+
+void gmpc_launch_lstm_bwd(int Bc, const CriticDesc& cd, const float* gates, const float* cs,
+                          const float* dhT, float* dz, float* dxseq, hipStream_t s) {
+  constexpr int R4 = GMPC_CR4;
+  const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
+  const size_t lds = 2 * (size_t)GMPC_THREADS * R4 * sizeof(float4);
+  hipLaunchKernelGGL(k_lstm_bwd<R4>, dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, gates, cs, dhT,
+                     dz, dxseq);
+}
+
+// C[M][N] = sum_r A[r][:M]^T B[r][:N]; colsum[N] = sum_{r < cs_rows} B[r][:N] (optional).
+// part must hold nsplit*(M*N + N) floats.
+void gmpc_launch_wgrad(int rows, int M, int N, const float* A, int lda, const float* Bm, int ldb,
+                       float* C, float* colsum, int cs_rows, float* part, int max_split,
+                       hipStream_t s) {
+  int nsplit = (rows + 511) / 512;
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  int rps = (rows + nsplit - 1) / nsplit;
+  rps = (rps + 15) / 16 * 16;
+  nsplit = (rows + rps - 1) / rps;
+  float* cpart = part;
+  float* cspart = colsum ? part + (size_t)nsplit * M * N : nullptr;
+  hipLaunchKernelGGL(k_wgrad, dim3((M + 63) / 64, (N + 63) / 64, nsplit), dim3(GMPC_THREADS), 0, s,
+                     rows, M, N, A, lda, Bm, ldb, rps, cpart, cspart, cs_rows);
+  hipLaunchKernelGGL(k_reduce_splits, dim3((M * N + 255) / 256), dim3(256), 0, s, M * N, nsplit, cpart,
+                     C);
+  if (colsum)
+    hipLaunchKernelGGL(k_reduce_splits, dim3((N + 255) / 256), dim3(256), 0, s, N, nsplit, cspart,
+                       colsum);
+}
+
+void gmpc_launch_sum(int count, const float* v, float* out, int square, hipStream_t s) {
+  hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, count, v, out, square);
+}
+
+void gmpc_launch_adam(long count, float* p, const float* g, float* m, float* v, float scale,
+                      int step, float lr, float max_norm, float b1, float b2, float eps,
+                      float* scratch /* >= 257 floats */, hipStream_t s) {
+  const int nb = 256;
+  hipLaunchKernelGGL(k_sqsum_part, dim3(nb), dim3(GMPC_THREADS), 0, s, count, g, scale, scratch + 1);
+  hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, nb, scratch + 1, scratch, 0);
+  const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, count, p, g, m, v,
+                     scale, scratch, max_norm, lr, b1, b2, eps, bc1, bc2);
+}

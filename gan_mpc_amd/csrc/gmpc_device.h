@@ -1,0 +1,164 @@
+// Device-side building blocks shared by the gfx950 kernels of libgan_mpc_amd.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gan_mpc_amd.h"
+
+#define GMPC_MW 8          // 32-bit mask words per hidden layer (hidden width <= 256)
+#define GMPC_THREADS 256   // workgroup size of the MLP kernels (4 wavefronts)
+#define GMPC_TB 4          // trajectories per workgroup in the sequential kernels
+#define GMPC_ALPHA 1e-2f   // smoothing constant of the stage cost (reference cost_model.py:22)
+
+// A relu MLP as the kernels see it.  W[l] is the flax kernel (in,out) row-major, WT[l] its
+// transpose (out,in) row-major (built once per gmpc_set_params), b[l] the bias.
+struct MlpDesc {
+  int L;
+  int dims[GMPC_MAX_LAYERS + 1];
+  const float* W[GMPC_MAX_LAYERS];
+  const float* WT[GMPC_MAX_LAYERS];
+  const float* b[GMPC_MAX_LAYERS];
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ void fma4(float4& acc, float w, const float4& a) {
+  acc.x = fmaf(w, a.x, acc.x);
+  acc.y = fmaf(w, a.y, acc.y);
+  acc.z = fmaf(w, a.z, acc.z);
+  acc.w = fmaf(w, a.w, acc.w);
+}
+
+// out[j][r] += sum_k W[k][j] * act[k][r] for one output neuron j per thread and 4*R4 rows r.
+// W is (K,N) row-major in global memory: lanes read consecutive j (coalesced); act is an LDS
+// image [K][R4] of float4, read as a wave-wide broadcast.  k runs in increasing order, so the
+// result is a k-ordered fmaf chain per (j, r).
+template <int R4>
+__device__ __forceinline__ void dense_rows(const float* __restrict__ W, int K, int N, int j,
+                                           const float4* act, float4 (&acc)[R4]) {
+  if (j >= N) return;
+  const float* wp = W + j;
+  int k = 0;
+  for (; k + 4 <= K; k += 4) {
+    const float w0 = wp[(size_t)(k + 0) * N];
+    const float w1 = wp[(size_t)(k + 1) * N];
+    const float w2 = wp[(size_t)(k + 2) * N];
+    const float w3 = wp[(size_t)(k + 3) * N];
+#pragma unroll
+    for (int q = 0; q < R4; ++q) fma4(acc[q], w0, act[(k + 0) * R4 + q]);
+#pragma unroll
+    for (int q = 0; q < R4; ++q) fma4(acc[q], w1, act[(k + 1) * R4 + q]);
+#pragma unroll
+    for (int q = 0; q < R4; ++q) fma4(acc[q], w2, act[(k + 2) * R4 + q]);
+#pragma unroll
+    for (int q = 0; q < R4; ++q) fma4(acc[q], w3, act[(k + 3) * R4 + q]);
+  }
+  for (; k < K; ++k) {
+    const float w = wp[(size_t)k * N];
+#pragma unroll
+    for (int q = 0; q < R4; ++q) fma4(acc[q], w, act[k * R4 + q]);
+  }
+}
+
+// Same product for a narrow output (N << blockDim): the K range is split over NS = blockDim/N
+// thread groups, partial sums meet in LDS and are added in segment order (deterministic).
+// On return (after the trailing barrier) part[j*R4 + q] holds the sums; `part` needs
+// NS*N*R4 float4 of LDS and must not alias `act`.  All threads of the block must call it.
+template <int R4>
+__device__ __forceinline__ void dense_small(const float* __restrict__ W, int K, int N,
+                                            const float4* act, float4* part) {
+  const int tid = threadIdx.x;
+  int NS = blockDim.x / N;
+  if (NS > K) NS = K;
+  const int KS = (K + NS - 1) / NS;
+  const int j = tid % N, seg = tid / N;
+  if (seg < NS) {
+    float4 acc[R4];
+#pragma unroll
+    for (int q = 0; q < R4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int k0 = seg * KS;
+    const int k1 = min(K, k0 + KS);
+    for (int k = k0; k < k1; ++k) {
+      const float w = W[(size_t)k * N + j];
+#pragma unroll
+      for (int q = 0; q < R4; ++q) fma4(acc[q], w, act[k * R4 + q]);
+    }
+#pragma unroll
+    for (int q = 0; q < R4; ++q) part[(seg * N + j) * R4 + q] = acc[q];
+  }
+  __syncthreads();
+  const int NE = N * R4;
+  for (int e = tid; e < NE; e += blockDim.x) {
+    float4 s = part[e];
+    for (int sg = 1; sg < NS; ++sg) {
+      const float4 p = part[sg * NE + e];
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    part[e] = s;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float f4get(const float4& v, int c) {
+  return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
+}
+__device__ __forceinline__ void f4set(float4& v, int c, float x) {
+  if (c == 0) v.x = x; else if (c == 1) v.y = x; else if (c == 2) v.z = x; else v.w = x;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- kernel argument blocks (shared by the kernel units and gmpc_api.hip) ----
+struct TrajArgs {
+  int B, n, m, T;
+  MlpDesc dyn, cost;
+  const float* mpc_w;   // raw weights [3]
+  const float* goal;    // [B][T+1][n]
+  // plain rollout: x0, U in; X, costs, masks out
+  const float* x0;      // [B][n]
+  const float* U;       // [B][T][m]
+  float* X;             // [B][T+1][n]
+  float* costs;         // [B][T+1] or null
+  float* obj;           // [B]
+  uint32_t* masks;      // [B][T][Lh][GMPC_MW]
+  // line search (LS): X,U,masks,obj are the current iterate and are updated in place on accept
+  float* Uio;           // [B][T][m]
+  const float* Kg;      // [B][T][m][n]
+  const float* kg;      // [B][T][m]
+  float* Xc;            // candidate buffers
+  float* Uc;
+  uint32_t* maskc;
+  const int* active;    // [B] or null
+  float* alpha;         // [B] out
+  float* obj_step;      // [B] out
+  float* U_step;        // [B] out
+  int* iters;           // [B] in/out
+  float alpha_0, alpha_min;
+};
+
+struct RiccatiArgs {
+  int B, n, m, T, mode;
+  const float* X; const float* U; const float* goal; const float* mpc_w;
+  const float* AB; const float* QT; const float* qT;
+  const int* active;
+  float* K; float* k; float* grad; float* adj;   // mode 0 outputs (may be null)
+  // iLQR continuation test (mode 0, optional: cont != null)
+  int* cont; const int* iters; const float* obj; const float* alpha; const float* obj_step;
+  const float* U_step;
+  gmpc_ilqr_opts opts;
+  // mode 1
+  const float* Bvec;   // [B][T][m]
+  float* Hout;         // [B][T][m]
+  float* dX;           // [B][T+1][n]
+};
+
+struct CriticDesc {
+  int n, F, T1;              // input size, lstm features, sequence length T+1
+  const float* Wcat;         // [(n+F)][4F]
+  const float* WcatT;        // [4F][(n+F)]
+  const float* b;            // [4F]
+  MlpDesc head;              // dims[0] = F ... dims[L] = 1
+};

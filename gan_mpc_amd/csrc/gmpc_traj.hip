@@ -1,0 +1,328 @@
+// Sequential-in-time trajectory kernels: rollout + cost, and the DDP line search.
+//
+// One 256-thread workgroup owns GMPC_TB = 4 trajectories for the whole horizon.  The state and
+// control of the current step live in LDS as float4 (one component per trajectory), every layer is
+// "one output neuron per thread": the weight row is read coalesced from L2 once and reused for
+// the four trajectories from registers.  relu sign bits leave the kernel as ballot bitmasks so the
+// backward Jacobian chain never recomputes the forward pass.
+//
+// Reference arithmetic: dynamics/nn.py:27-34 (residual relu MLP), cost/cost_model.py:20-42,
+// cost/nn.py:23-29, trajax rollout / evaluate / ddp_rollout / line_search_ddp as called from
+// policy/optimizers.py:19,26-29,55.
+#include "gmpc_device.h"
+
+
+// One hidden layer for the 4 trajectories of the block: z = act_in . W + b; mask bits; relu.
+__device__ __forceinline__ void hidden_layer(const float* W, const float* bias, int K, int N,
+                                             const float4* actIn, float4* actOut, uint32_t* mrow[4],
+                                             bool wmask[4]) {
+  const int j = threadIdx.x;
+  const bool valid = j < N;
+  const float bj = valid ? bias[j] : 0.f;
+  float4 acc[1] = {make_float4(bj, bj, bj, bj)};
+  dense_rows<1>(W, K, N, j, actIn, acc);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool pos = valid && f4get(acc[0], c) > 0.f;
+    const unsigned long long bal = __ballot(pos);
+    if (lane == 0 && wmask[c] && mrow[c] != nullptr) {
+      mrow[c][2 * wave] = (uint32_t)bal;
+      mrow[c][2 * wave + 1] = (uint32_t)(bal >> 32);
+    }
+  }
+  if (valid)
+    actOut[j] = make_float4(fmaxf(acc[0].x, 0.f), fmaxf(acc[0].y, 0.f), fmaxf(acc[0].z, 0.f),
+                            fmaxf(acc[0].w, 0.f));
+}
+
+template <bool LS>
+__global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
+  __shared__ float4 actA[GMPC_THREADS];
+  __shared__ float4 actB[GMPC_THREADS];
+  __shared__ float4 part[GMPC_THREADS];
+  __shared__ float4 xcur[64];
+  __shared__ float s_obj[GMPC_TB], s_objold[GMPC_TB], s_alpha[GMPC_TB], s_ustep[GMPC_TB];
+  __shared__ float s_us[GMPC_THREADS / 64];
+  __shared__ int s_run[GMPC_TB], s_acc[GMPC_TB], s_ever[GMPC_TB], s_any;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n = a.n, m = a.m, T = a.T;
+  const int b0 = blockIdx.x * GMPC_TB;
+  int bi[4];
+  bool inb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    inb[c] = (b0 + c) < a.B;
+    bi[c] = inb[c] ? (b0 + c) : (a.B - 1);  // clamp reads of the tail block
+  }
+  const int Lh = a.dyn.L - 1;
+  const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]), w2 = sigmoidf_(a.mpc_w[2]);
+
+  if (LS) {
+    if (tid < GMPC_TB) {
+      const int b = bi[tid];
+      const bool act = inb[tid] && (a.active == nullptr || a.active[b] != 0);
+      float o = a.obj[b];
+      if (isnan(o)) o = INFINITY;
+      s_objold[tid] = o;
+      s_alpha[tid] = a.alpha_0;
+      s_run[tid] = (act && a.alpha_0 > a.alpha_min) ? 1 : 0;
+      s_acc[tid] = 0;
+      s_ever[tid] = 0;
+      s_ustep[tid] = 0.f;
+      if (act) a.iters[b] += 1;
+    }
+    __syncthreads();
+    if (tid == 0) s_any = s_run[0] | s_run[1] | s_run[2] | s_run[3];
+    __syncthreads();
+  }
+
+  while (true) {
+    if (LS && !s_any) break;
+    bool wm[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wm[c] = LS ? (s_run[c] != 0) : inb[c];
+    // ---- initial state
+    if (tid < n) {
+      const float* xs = LS ? a.X : a.x0;
+      const size_t st = LS ? (size_t)(T + 1) * n : (size_t)n;
+      float4 v = make_float4(xs[bi[0] * st + tid], xs[bi[1] * st + tid], xs[bi[2] * st + tid],
+                             xs[bi[3] * st + tid]);
+      xcur[tid] = v;
+      if (!LS) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (inb[c]) a.X[(size_t)bi[c] * (T + 1) * n + tid] = f4get(v, c);
+      }
+    }
+    float objacc = 0.f;  // lane 0 of wave c accumulates trajectory c
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+      // ---- controls and layer-0 input
+      if (tid < n) actA[tid] = xcur[tid];
+      if (tid < GMPC_TB * m) {
+        const int c = tid / m, j = tid % m;
+        const size_t ub = ((size_t)bi[c] * T + t) * m + j;
+        float u;
+        if (LS) {
+          const float* Kr = a.Kg + ub * n;
+          const float* Xo = a.X + ((size_t)bi[c] * (T + 1) + t) * n;
+          float du = s_alpha[c] * a.kg[ub];
+          for (int i = 0; i < n; ++i) du = fmaf(Kr[i], f4get(xcur[i], c) - Xo[i], du);
+          u = a.Uio[ub] + du;
+          if (wm[c]) a.Uc[ub] = u;
+        } else {
+          u = a.U[ub];
+        }
+        f4set(actA[n + j], c, u);
+      }
+      __syncthreads();
+      // ---- stage cost of (x_t, u_t): wave c handles trajectory c
+      {
+        const int c = wave;
+        float dd = 0.f, uu = 0.f;
+        const float* g = a.goal + ((size_t)bi[c] * (T + 1) + t) * n;
+        for (int i = lane; i < n; i += 64) {
+          const float d = f4get(actA[i], c) - g[i];
+          dd = fmaf(d, d, dd);
+        }
+        for (int j = lane; j < m; j += 64) {
+          const float u = f4get(actA[n + j], c);
+          uu = fmaf(u, u, uu);
+        }
+        dd = wave_sum(dd);
+        uu = wave_sum(uu);
+        const float al = GMPC_ALPHA;
+        const float cst = w0 * (sqrtf(uu + al * al) - al) + w1 * (sqrtf(dd + al * al) - al);
+        objacc += cst;
+        if (!LS && lane == 0 && inb[c] && a.costs) a.costs[(size_t)bi[c] * (T + 1) + t] = cst;
+      }
+      // ---- hidden layers
+      float4* in = actA;
+      float4* out = actB;
+      for (int l = 0; l < Lh; ++l) {
+        uint32_t* mrow[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          mrow[c] = (LS ? a.maskc : a.masks) + (((size_t)bi[c] * T + t) * Lh + l) * GMPC_MW;
+        hidden_layer(a.dyn.W[l], a.dyn.b[l], a.dyn.dims[l], a.dyn.dims[l + 1], in, out, mrow, wm);
+        __syncthreads();
+        float4* tmp = in; in = out; out = tmp;
+      }
+      // ---- output layer + residual
+      dense_small<1>(a.dyn.W[Lh], a.dyn.dims[Lh], n, in, part);
+      if (tid < n) {
+        const float bj = a.dyn.b[Lh][tid];
+        float4 v = part[tid];
+        const float4 xo = xcur[tid];
+        v.x = (v.x + bj) + xo.x; v.y = (v.y + bj) + xo.y;
+        v.z = (v.z + bj) + xo.z; v.w = (v.w + bj) + xo.w;
+        xcur[tid] = v;
+        float* Xo = LS ? a.Xc : a.X;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (wm[c]) Xo[((size_t)bi[c] * (T + 1) + t + 1) * n + tid] = f4get(v, c);
+      }
+      __syncthreads();
+    }
+    // ---- terminal cost w2 * |cost_mlp(x_T)|^2
+    {
+      float4* in = xcur;
+      float4* out = actA;
+      const int Lc = a.cost.L - 1;
+      uint32_t* nomask[4] = {nullptr, nullptr, nullptr, nullptr};
+      bool nowm[4] = {false, false, false, false};
+      for (int l = 0; l < Lc; ++l) {
+        hidden_layer(a.cost.W[l], a.cost.b[l], a.cost.dims[l], a.cost.dims[l + 1], in, out, nomask,
+                     nowm);
+        __syncthreads();
+        in = out;
+        out = (out == actA) ? actB : actA;
+      }
+      const int fo = a.cost.dims[Lc + 1];
+      dense_small<1>(a.cost.W[Lc], a.cost.dims[Lc], fo, in, part);
+      const int c = wave;
+      float yy = 0.f;
+      for (int r = lane; r < fo; r += 64) {
+        const float y = f4get(part[r], c) + a.cost.b[Lc][r];
+        yy = fmaf(y, y, yy);
+      }
+      yy = wave_sum(yy);
+      const float cst = w2 * yy;
+      objacc += cst;
+      if (lane == 0) {
+        if (!LS) {
+          if (inb[c]) {
+            if (a.costs) a.costs[(size_t)bi[c] * (T + 1) + T] = cst;
+            a.obj[bi[c]] = objacc;
+          }
+        } else {
+          s_obj[c] = objacc;
+        }
+      }
+    }
+    if (!LS) break;
+    __syncthreads();
+    // ---- accept / backtrack decision per trajectory
+    if (tid < GMPC_TB) {
+      const int c = tid;
+      s_acc[c] = 0;
+      if (s_run[c]) {
+        const float oo = s_objold[c];
+        float on = s_obj[c];
+        if (isnan(on)) on = oo;
+        const bool acc = on < oo;
+        s_alpha[c] *= 0.5f;
+        const float objr = fminf(on, oo);
+        if (acc) {
+          s_acc[c] = 1;
+          s_ever[c] = 1;
+          a.obj[bi[c]] = on;
+          a.obj_step[bi[c]] = fabsf(on - oo);
+        }
+        s_run[c] = ((objr >= oo) && (s_alpha[c] > a.alpha_min)) ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    // ---- commit accepted candidates
+    for (int c = 0; c < GMPC_TB; ++c) {
+      if (!s_acc[c]) continue;
+      const size_t b = bi[c];
+      float* Xd = a.X + b * (T + 1) * n;
+      const float* Xs = a.Xc + b * (T + 1) * n;
+      for (int e = n + tid; e < (T + 1) * n; e += blockDim.x) Xd[e] = Xs[e];
+      float us = 0.f;
+      float* Ud = a.Uio + b * T * m;
+      const float* Us = a.Uc + b * T * m;
+      for (int e = tid; e < T * m; e += blockDim.x) {
+        const float un = Us[e], d = un - Ud[e];
+        us = fmaf(d, d, us);
+        Ud[e] = un;
+      }
+      uint32_t* Md = a.masks + b * T * Lh * GMPC_MW;
+      const uint32_t* Ms = a.maskc + b * T * Lh * GMPC_MW;
+      for (int e = tid; e < T * Lh * GMPC_MW; e += blockDim.x) Md[e] = Ms[e];
+      us = wave_sum(us);
+      if (lane == 0) s_us[wave] = us;
+      __syncthreads();  // s_acc is block-uniform, so every thread reaches this barrier
+      if (tid == 0) s_ustep[c] = (s_us[0] + s_us[1]) + (s_us[2] + s_us[3]);
+    }
+    if (tid == 0) s_any = s_run[0] | s_run[1] | s_run[2] | s_run[3];
+    __syncthreads();
+  }
+  if (LS) {
+    __syncthreads();
+    if (tid < GMPC_TB && inb[tid]) {
+      const int b = bi[tid];
+      const bool act = (a.active == nullptr || a.active[b] != 0);
+      if (act) {
+        a.alpha[b] = s_alpha[tid];
+        if (s_ever[tid]) {
+          a.U_step[b] = sqrtf(s_ustep[tid]);
+        } else {
+          a.U_step[b] = 0.f;
+          a.obj_step[b] = 0.f;
+        }
+      }
+    }
+  }
+}
+
+// Forward pass at given (x, u) pairs, masks only: used when gmpc_lqr_backward is handed a
+// trajectory that did not come from this context's rollout.  4 samples per workgroup.
+__global__ __launch_bounds__(GMPC_THREADS) void k_masks(int NS, int n, int m, int T, MlpDesc dyn,
+                                                        const float* X, const float* U,
+                                                        uint32_t* masks) {
+  __shared__ float4 actA[GMPC_THREADS];
+  __shared__ float4 actB[GMPC_THREADS];
+  const int tid = threadIdx.x;
+  const int s0 = blockIdx.x * 4;
+  int si[4];
+  bool in_[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    in_[c] = s0 + c < NS;
+    si[c] = in_[c] ? s0 + c : NS - 1;
+  }
+  if (tid < n + m) {
+    float4 v;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int b = si[c] / T, t = si[c] % T;
+      const float x = tid < n ? X[((size_t)b * (T + 1) + t) * n + tid]
+                              : U[((size_t)b * T + t) * m + (tid - n)];
+      f4set(v, c, x);
+    }
+    actA[tid] = v;
+  }
+  __syncthreads();
+  const int Lh = dyn.L - 1;
+  float4* in = actA;
+  float4* out = actB;
+  for (int l = 0; l < Lh; ++l) {
+    uint32_t* mrow[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mrow[c] = masks + ((size_t)si[c] * Lh + l) * GMPC_MW;
+    hidden_layer(dyn.W[l], dyn.b[l], dyn.dims[l], dyn.dims[l + 1], in, out, mrow, in_);
+    __syncthreads();
+    float4* tmp = in; in = out; out = tmp;
+  }
+}
+
+// Host-side launchers ---------------------------------------------------------------------------
+void gmpc_launch_rollout(const TrajArgs& a, hipStream_t s) {
+  const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
+  hipLaunchKernelGGL(k_traj<false>, dim3(grid), dim3(GMPC_THREADS), 0, s, a);
+}
+void gmpc_launch_linesearch(const TrajArgs& a, hipStream_t s) {
+  const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
+  hipLaunchKernelGGL(k_traj<true>, dim3(grid), dim3(GMPC_THREADS), 0, s, a);
+}
+void gmpc_launch_masks(int B, int n, int m, int T, const MlpDesc& dyn, const float* X,
+                       const float* U, uint32_t* masks, hipStream_t s) {
+  const int NS = B * T;
+  hipLaunchKernelGGL(k_masks, dim3((NS + 3) / 4), dim3(GMPC_THREADS), 0, s, NS, n, m, T, dyn, X, U,
+                     masks);
+}

@@ -1,0 +1,198 @@
+"""Thin host wrapper around one ``gmpc_ctx``: torch tensors own the device memory and the stream,
+every method is a single call through the C ABI (include/gan_mpc_amd.h).
+
+torch is plumbing only here (device buffers, ``torch.cuda.current_stream``); no arithmetic on the
+hot path is done by torch.
+"""
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import IlqrOpts, Shape
+
+# trajax iLQR keywords exactly as the reference passes them (policy/eval.py:10-20)
+TRAJAX_iLQR_KWARGS = {
+    "maxiter": 100,
+    "grad_norm_threshold": 1e-4,
+    "relative_grad_norm_threshold": 0.0,
+    "obj_step_threshold": 0.0,
+    "inputs_step_threshold": 0.0,
+    "make_psd": False,
+    "psd_delta": 0.0,
+    "alpha_0": 1.0,
+    "alpha_min": 0.00005,
+}
+
+
+def make_shape(n, m, T, dyn_dims, cost_dims, lstm_features=0, head_dims=None):
+    s = Shape()
+    s.n, s.m, s.T = int(n), int(m), int(T)
+    s.dyn_layers = len(dyn_dims) - 1
+    s.cost_layers = len(cost_dims) - 1
+    for i, d in enumerate(dyn_dims):
+        s.dyn_dims[i] = int(d)
+    for i, d in enumerate(cost_dims):
+        s.cost_dims[i] = int(d)
+    s.lstm_features = int(lstm_features)
+    if lstm_features:
+        head_dims = list(head_dims or [lstm_features, 1])
+        s.head_layers = len(head_dims) - 1
+        for i, d in enumerate(head_dims):
+            s.head_dims[i] = int(d)
+    return s
+
+
+def make_opts(kwargs=None):
+    kw = dict(TRAJAX_iLQR_KWARGS)
+    if kwargs:
+        kw.update(kwargs)
+    o = IlqrOpts()
+    o.maxiter = int(kw["maxiter"])
+    o.grad_norm_threshold = float(kw["grad_norm_threshold"])
+    o.relative_grad_norm_threshold = float(kw["relative_grad_norm_threshold"])
+    o.obj_step_threshold = float(kw["obj_step_threshold"])
+    o.inputs_step_threshold = float(kw["inputs_step_threshold"])
+    o.make_psd = int(bool(kw["make_psd"]))
+    o.psd_delta = float(kw["psd_delta"])
+    o.alpha_0 = float(kw["alpha_0"])
+    o.alpha_min = float(kw["alpha_min"])
+    return o
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32) and t.is_contiguous(), \
+        "C-ABI buffers must be contiguous fp32/int32 device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One context on one GPU.  All tensor arguments are contiguous fp32 CUDA(HIP) tensors."""
+
+    def __init__(self, n, m, T, dyn_dims, cost_dims, max_batch, lstm_features=0, head_dims=None,
+                 device=None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.GmpcError("no HIP device visible to torch; gan_mpc_amd has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.shape = make_shape(n, m, T, dyn_dims, cost_dims, lstm_features, head_dims)
+        self.n, self.m, self.T = int(n), int(m), int(T)
+        self.max_batch = int(max_batch)
+        self.dyn_count = self.lib.gmpc_param_count(C.byref(self.shape), 0)
+        self.cost_count = self.lib.gmpc_param_count(C.byref(self.shape), 1)
+        self.critic_count = self.lib.gmpc_param_count(C.byref(self.shape), 2) if lstm_features else 0
+        ctx = C.c_void_p()
+        _lib.check(self.lib.gmpc_create(C.byref(self.shape), self.max_batch, self.device.index,
+                                        C.byref(ctx)))
+        self.ctx = ctx
+        self._bound = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.gmpc_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def new(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def to_dev(self, a, dtype=torch.float32):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device).contiguous()
+
+    def set_params(self, mpc_w, dyn, cost):
+        assert mpc_w.numel() == 3 and dyn.numel() == self.dyn_count and cost.numel() == self.cost_count
+        self._bound = (mpc_w, dyn, cost)  # keep the tensors alive: the ctx holds raw pointers
+        _lib.check(self.lib.gmpc_set_params(self.ctx, _ptr(mpc_w), _ptr(dyn), _ptr(cost),
+                                            self._stream()))
+
+    def rollout_cost(self, x0, U, goal, X=None, costs=None):
+        B = x0.shape[0]
+        X = self.new(B, self.T + 1, self.n) if X is None else X
+        costs = self.new(B, self.T + 1) if costs is None else costs
+        _lib.check(self.lib.gmpc_rollout_cost(self.ctx, B, _ptr(x0), _ptr(U), _ptr(goal), _ptr(X),
+                                              _ptr(costs), self._stream()))
+        return X, costs
+
+    def lqr_backward(self, X, U, goal, after_rollout=False, out=None):
+        B = X.shape[0]
+        n, m, T = self.n, self.m, self.T
+        if out is None:
+            out = dict(K=self.new(B, T, m, n), k=self.new(B, T, m), grad=self.new(B, T, m),
+                       adjoints=self.new(B, T + 1, n), AB=self.new(B, T, n, n + m))
+        fn = self.lib.gmpc_lqr_backward_after_rollout if after_rollout else self.lib.gmpc_lqr_backward
+        _lib.check(fn(self.ctx, B, _ptr(X), _ptr(U), _ptr(goal), _ptr(out["K"]), _ptr(out["k"]),
+                      _ptr(out["grad"]), _ptr(out["adjoints"]), _ptr(out.get("AB")), self._stream()))
+        return out
+
+    def ilqr_solve(self, x0, U, goal, kwargs=None):
+        B = x0.shape[0]
+        n, m, T = self.n, self.m, self.T
+        opts = make_opts(kwargs)
+        out = dict(X=self.new(B, T + 1, n), U=self.new(B, T, m), obj=self.new(B),
+                   grad=self.new(B, T, m), adjoints=self.new(B, T + 1, n),
+                   iterations=self.new(B, dtype=torch.int32))
+        _lib.check(self.lib.gmpc_ilqr_solve(
+            self.ctx, B, _ptr(x0), _ptr(U), _ptr(goal), C.byref(opts), _ptr(out["X"]), _ptr(out["U"]),
+            _ptr(out["obj"]), _ptr(out["grad"]), _ptr(out["adjoints"]), _ptr(out["iterations"]),
+            self._stream()))
+        return out
+
+    def bilevel_grad(self, B, loss_kind, desired=None, critic=None, sign=1.0):
+        loss = self.new(B)
+        grad_sum = self.new(3 + self.cost_count)
+        _lib.check(self.lib.gmpc_bilevel_grad(self.ctx, B, int(loss_kind), _ptr(desired), _ptr(critic),
+                                              float(sign), _ptr(loss), _ptr(grad_sum), self._stream()))
+        return loss, grad_sum
+
+    def critic_loss_grad(self, xseq, label, critic):
+        Bc = xseq.shape[0]
+        loss_sum = self.new(1)
+        grad_sum = self.new(self.critic_count)
+        _lib.check(self.lib.gmpc_critic_loss_grad(self.ctx, Bc, _ptr(xseq), _ptr(label), _ptr(critic),
+                                                  _ptr(loss_sum), _ptr(grad_sum), self._stream()))
+        return loss_sum, grad_sum
+
+    def critic_score_vjp(self, xseq, critic, want_dx=True):
+        Bc = xseq.shape[0]
+        score = self.new(Bc)
+        dx = self.new(Bc, self.T + 1, self.n) if want_dx else None
+        _lib.check(self.lib.gmpc_critic_score_vjp(self.ctx, Bc, _ptr(xseq), _ptr(critic), _ptr(score),
+                                                  _ptr(dx), self._stream()))
+        return score, dx
+
+    def adam_clip_step(self, params, grad, m, v, step, lr, grad_scale=1.0, max_norm=100.0, b1=0.9,
+                       b2=0.999, eps=1e-8):
+        _lib.check(self.lib.gmpc_adam_clip_step(
+            self.ctx, params.numel(), _ptr(params), _ptr(grad), _ptr(m), _ptr(v), float(grad_scale),
+            int(step), float(lr), float(max_norm), float(b1), float(b2), float(eps), self._stream()))
+
+    def debug_buffer(self, which, shape):
+        """Copy of one of the ctx's internal solution buffers (see gmpc_debug_buffer)."""
+        p = self.lib.gmpc_debug_buffer(self.ctx, which)
+        if not p:
+            raise _lib.GmpcError(f"no debug buffer {which}")
+        n = int(np.prod(shape))
+        torch.cuda.synchronize(self.device)
+        view = torch.as_tensor(_RawDevBuffer(p, n), device=self.device)
+        return view.clone().reshape(shape)
+
+
+class _RawDevBuffer:
+    """__cuda_array_interface__ view of a raw fp32 device pointer."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {
+            "shape": (count,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}

@@ -1,0 +1,147 @@
+"""Flax-style parameter pytrees <-> the flat fp32 vectors of the C ABI.
+
+The reference keeps parameters as ``{"params": {"Dense_k": {"kernel": (in,out), "bias": (out,)}}}``
+trees (flax ``Dense`` auto-naming, reference cost/nn.py:23-29, dynamics/nn.py:27-34) and the critic's
+scanned ``OptimizedLSTMCell`` with kernels ``ii,if,ig,io`` (no bias) and ``hi,hf,hg,ho`` (+bias)
+(reference critic/nn.py:28-42; names as in flax 0.7.2).  The C ABI wants one flat
+vector per model: kernel (in,out) row-major then bias, layer after layer; the critic as
+Wx[n][4F] | Wh[F][4F] | b[4F] with gate order i,f,g,o, then the head's Dense layers.
+"""
+
+import numpy as np
+
+GATES = ("i", "f", "g", "o")
+LSTM_SCOPE = "ScanOptimizedLSTMCell_0"
+
+
+def mlp_dims(tree):
+    p = tree["params"]
+    dims = []
+    for k in range(len(p)):
+        kern = np.asarray(p[f"Dense_{k}"]["kernel"])
+        if k == 0:
+            dims.append(kern.shape[0])
+        dims.append(kern.shape[1])
+    return dims
+
+
+def pack_mlp(tree):
+    p = tree["params"]
+    out = []
+    for k in range(len(p)):
+        d = p[f"Dense_{k}"]
+        out.append(np.asarray(d["kernel"], np.float32).reshape(-1))
+        out.append(np.asarray(d["bias"], np.float32).reshape(-1))
+    return np.concatenate(out)
+
+
+def unpack_mlp(flat, dims):
+    flat = np.asarray(flat, np.float32)
+    p, off = {}, 0
+    for k, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        kern = flat[off:off + a * b].reshape(a, b).copy()
+        off += a * b
+        bias = flat[off:off + b].copy()
+        off += b
+        p[f"Dense_{k}"] = {"kernel": kern, "bias": bias}
+    assert off == flat.size, (off, flat.size)
+    return {"params": p}
+
+
+def layers_to_tree(layers):
+    """[(W, b), ...] -> flax tree."""
+    return {"params": {f"Dense_{k}": {"kernel": np.asarray(W), "bias": np.asarray(b)}
+                       for k, (W, b) in enumerate(layers)}}
+
+
+def tree_to_layers(tree):
+    p = tree["params"]
+    return [(np.asarray(p[f"Dense_{k}"]["kernel"]), np.asarray(p[f"Dense_{k}"]["bias"]))
+            for k in range(len(p))]
+
+
+def _lstm_scope(p):
+    for k in p:
+        if "LSTM" in k:
+            return k
+    raise KeyError("no LSTM cell scope in critic params")
+
+
+def pack_critic(tree):
+    p = tree["params"]
+    cell = p[_lstm_scope(p)]
+    Wx = np.concatenate([np.asarray(cell["i" + g]["kernel"], np.float32) for g in GATES], axis=1)
+    Wh = np.concatenate([np.asarray(cell["h" + g]["kernel"], np.float32) for g in GATES], axis=1)
+    b = np.concatenate([np.asarray(cell["h" + g]["bias"], np.float32) for g in GATES])
+    out = [Wx.reshape(-1), Wh.reshape(-1), b]
+    k = 0
+    while f"Dense_{k}" in p:
+        out.append(np.asarray(p[f"Dense_{k}"]["kernel"], np.float32).reshape(-1))
+        out.append(np.asarray(p[f"Dense_{k}"]["bias"], np.float32).reshape(-1))
+        k += 1
+    return np.concatenate(out)
+
+
+def critic_dims(tree):
+    p = tree["params"]
+    cell = p[_lstm_scope(p)]
+    n, F = np.asarray(cell["ii"]["kernel"]).shape
+    head = [F]
+    k = 0
+    while f"Dense_{k}" in p:
+        head.append(np.asarray(p[f"Dense_{k}"]["kernel"]).shape[1])
+        k += 1
+    return n, F, head
+
+
+def unpack_critic(flat, n, F, head_dims, scope=LSTM_SCOPE):
+    flat = np.asarray(flat, np.float32)
+    off = 0
+    Wx = flat[off:off + n * 4 * F].reshape(n, 4 * F)
+    off += n * 4 * F
+    Wh = flat[off:off + F * 4 * F].reshape(F, 4 * F)
+    off += F * 4 * F
+    b = flat[off:off + 4 * F]
+    off += 4 * F
+    cell = {}
+    for gi, g in enumerate(GATES):
+        cell["i" + g] = {"kernel": Wx[:, gi * F:(gi + 1) * F].copy()}
+        cell["h" + g] = {"kernel": Wh[:, gi * F:(gi + 1) * F].copy(),
+                         "bias": b[gi * F:(gi + 1) * F].copy()}
+    p = {scope: cell}
+    for k, (a, c) in enumerate(zip(head_dims[:-1], head_dims[1:])):
+        kern = flat[off:off + a * c].reshape(a, c).copy()
+        off += a * c
+        bias = flat[off:off + c].copy()
+        off += c
+        p[f"Dense_{k}"] = {"kernel": kern, "bias": bias}
+    assert off == flat.size, (off, flat.size)
+    return {"params": p}
+
+
+def critic_oracle_to_tree(cr, scope=LSTM_SCOPE):
+    """dict(Wx, Wh, b, head) (the layout the tests' oracle uses) -> flax tree."""
+    F = cr["Wh"].shape[0]
+    cell = {}
+    for gi, g in enumerate(GATES):
+        cell["i" + g] = {"kernel": np.asarray(cr["Wx"][:, gi * F:(gi + 1) * F])}
+        cell["h" + g] = {"kernel": np.asarray(cr["Wh"][:, gi * F:(gi + 1) * F]),
+                         "bias": np.asarray(cr["b"][gi * F:(gi + 1) * F])}
+    p = {scope: cell}
+    for k, (W, b) in enumerate(cr["head"]):
+        p[f"Dense_{k}"] = {"kernel": np.asarray(W), "bias": np.asarray(b)}
+    return {"params": p}
+
+
+def critic_tree_to_oracle(tree):
+    p = tree["params"]
+    cell = p[_lstm_scope(p)]
+    Wx = np.concatenate([np.asarray(cell["i" + g]["kernel"]) for g in GATES], axis=1)
+    Wh = np.concatenate([np.asarray(cell["h" + g]["kernel"]) for g in GATES], axis=1)
+    b = np.concatenate([np.asarray(cell["h" + g]["bias"]) for g in GATES])
+    head = []
+    k = 0
+    while f"Dense_{k}" in p:
+        head.append((np.asarray(p[f"Dense_{k}"]["kernel"]), np.asarray(p[f"Dense_{k}"]["bias"])))
+        k += 1
+    return dict(Wx=Wx, Wh=Wh, b=b, head=head)

@@ -1,0 +1,156 @@
+/*
+ * gan_mpc_amd.h -- C ABI of libgan_mpc_amd.so: the MI355X (gfx950) implementation of the
+ * GAN-MPC inner loop of returaj/gan_mpc.
+ *
+ * The reference has no FFI: its boundary is a Python object protocol.  Each entry
+ * point below names the reference function(s) whose arithmetic it replaces (paths relative to the
+ * reference repository root); the gan_mpc_amd Python package rebuilds the reference's Python protocol on top of
+ * these calls through ctypes (see INTEGRATION.md for the binding a maintainer would add).
+ *
+ * Conventions
+ *  - Every buffer is caller-owned DEVICE memory, fp32, row-major, unless stated otherwise.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only enqueue
+ *    work; nothing synchronises unless stated.
+ *  - Return value: 0 on success, a negative GMPC_E* code on failure; gmpc_last_error() returns a
+ *    thread-local description of the last failure.  No C++ exception crosses this ABI.
+ *  - A gmpc_ctx belongs to one GPU and is thread-compatible (one caller at a time).
+ *  - There is no CPU fallback: without a HIP device every compute entry point fails.
+ *
+ * Parameter layouts (flat fp32 vectors, flax Dense order: kernel (in,out) row-major, then bias):
+ *   dyn    : for l in 0..dyn_layers-1:  W_l[dims[l]][dims[l+1]], b_l[dims[l+1]]
+ *            dims[0] = n+m, dims[last] = n          (reference dynamics/nn.py:27-34)
+ *   cost   : same, dims[0] = n, dims[last] = fout   (reference cost/nn.py:23-29)
+ *   mpc_w  : 3 raw weights (action, state, terminal) (reference gan/runner.py:41, cost_model.py:37)
+ *   critic : Wx[n][4F], Wh[F][4F], b[4F] (gate order i,f,g,o), then the head's Dense layers
+ *            head_dims[0] = F, head_dims[last] = 1   (reference critic/nn.py:28-42)
+ */
+#ifndef GAN_MPC_AMD_H
+#define GAN_MPC_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMPC_MAX_LAYERS 8
+
+enum {
+  GMPC_OK = 0,
+  GMPC_EINVAL = -1,      /* bad argument / unsupported shape */
+  GMPC_ENODEV = -2,      /* no usable HIP device */
+  GMPC_EHIP = -3,        /* a HIP runtime call failed */
+  GMPC_ENOMEM = -4
+};
+
+typedef struct gmpc_ctx gmpc_ctx;
+
+typedef struct gmpc_shape {
+  int n;                /* state size (xc size; the MLP dynamics has an empty carry) */
+  int m;                /* action size */
+  int T;                /* horizon H */
+  int dyn_layers;       /* number of Dense layers of the dynamics MLP */
+  int dyn_dims[GMPC_MAX_LAYERS + 1];
+  int cost_layers;
+  int cost_dims[GMPC_MAX_LAYERS + 1];
+  int lstm_features;    /* F */
+  int head_layers;      /* Dense layers after the LSTM (>= 1, last one has 1 output) */
+  int head_dims[GMPC_MAX_LAYERS + 1];
+} gmpc_shape;
+
+/* trajax iLQR keyword set, reference policy/eval.py:10-20 */
+typedef struct gmpc_ilqr_opts {
+  int maxiter;
+  float grad_norm_threshold;
+  float relative_grad_norm_threshold;
+  float obj_step_threshold;
+  float inputs_step_threshold;
+  int make_psd;          /* must be 0 (the reference never sets it) */
+  float psd_delta;
+  float alpha_0;
+  float alpha_min;
+} gmpc_ilqr_opts;
+
+const char* gmpc_last_error(void);
+const char* gmpc_version(void);
+
+/* Sizes of the flat parameter vectors for a shape: which = 0 dyn, 1 cost, 2 critic. */
+long gmpc_param_count(const gmpc_shape* shape, int which);
+
+/* One context per GPU.  Allocates the workspace for up to max_batch trajectories
+ * (and 2*max_batch critic sequences). */
+int gmpc_create(const gmpc_shape* shape, int max_batch, int device, gmpc_ctx** out);
+int gmpc_destroy(gmpc_ctx* ctx);
+
+/* Bind the model parameters used by the trajectory kernels (device pointers; they must stay valid
+ * and unchanged until the next gmpc_set_params).  Builds the transposed weight copies the backward
+ * chains read.  Replaces the params-dict unwrapping of policy/eval.py:64-73. */
+int gmpc_set_params(gmpc_ctx* ctx, const float* mpc_w, const float* dyn, const float* cost,
+                    void* stream);
+
+/* a1-a4,a7: X = rollout(dynamics, U, x0); costs[t] = get_cost(X[t], pad(U)[t], t).
+ * Replaces trajax rollout/evaluate as called at policy/optimizers.py:24-31 with
+ * dynamics/nn.py:27-34, cost/cost_model.py:20-42, cost/nn.py:23-29.
+ *   x0 [B][n], U [B][T][m], goal [B][T+1][n]  ->  X [B][T+1][n], costs [B][T+1]            */
+int gmpc_rollout_cost(gmpc_ctx* ctx, int B, const float* x0, const float* U, const float* goal,
+                      float* X, float* costs, void* stream);
+
+/* One iLQR backward pass at an arbitrary trajectory (X, U): linearise the dynamics (the relu sign
+ * masks are recomputed from (X, U)), quadratise the cost, run the time-varying LQR (Riccati)
+ * recursion and the adjoint recursion.
+ * Replaces trajax linearize/quadratize/tvlqr/adjoint inside trajax ilqr (policy/optimizers.py:19,55).
+ *   -> K [B][T][m][n], k [B][T][m], grad [B][T][m], adjoints [B][T+1][n]; any output may be NULL.
+ *   AB (optional) [B][T][n][n+m]: rows of [A_t | B_t] = d f/d[x,u]. */
+int gmpc_lqr_backward(gmpc_ctx* ctx, int B, const float* X, const float* U, const float* goal,
+                      float* K, float* k, float* grad, float* adjoints, float* AB, void* stream);
+
+/* Same as gmpc_lqr_backward, but reuses the relu sign masks that the immediately preceding
+ * gmpc_rollout_cost of this ctx produced for exactly this (X, U): the fused rollout + backward
+ * "step" of one iLQR iteration (what bench.py times). */
+int gmpc_lqr_backward_after_rollout(gmpc_ctx* ctx, int B, const float* X, const float* U,
+                                    const float* goal, float* K, float* k, float* grad,
+                                    float* adjoints, float* AB, void* stream);
+
+/* a6: full iLQR solve (policy/optimizers.py:10-21 -> trajax ilqr), one independent solve per
+ * trajectory (the reference's jax.vmap axis, policy/base.py:122-125).
+ *   U_init [B][T][m] -> X [B][T+1][n], U [B][T][m], obj [B], grad [B][T][m], adjoints [B][T+1][n],
+ *   iterations [B] (int32).  Synchronises the stream before returning. */
+int gmpc_ilqr_solve(gmpc_ctx* ctx, int B, const float* x0, const float* U_init, const float* goal,
+                    const gmpc_ilqr_opts* opts, float* X, float* U, float* obj, float* grad,
+                    float* adjoints, int* iterations, void* stream);
+
+/* a8-a11 (+a13/a16): upper-level loss and its bilevel gradient at the iLQR solution held by the ctx
+ * after gmpc_ilqr_solve (policy/optimizers.py:61-73,78-105), per trajectory; the batch mean of
+ * policy/base.py:126-127 is left to the caller (it is where the multi-GPU all-reduce goes).
+ *   loss_kind 0: L2 (norm/l2_policy.py:12-18), desired [B][T+1][n]
+ *   loss_kind 1: JS generator (gan/js_policy.py:60-68) with critic params `critic`
+ *   sign: +1 reproduces the reference as written, -1 the implicit-function gradient.
+ *   -> loss [B]; grad_sum [3 + cost_count]: SUM over the batch of d/d(mpc_w, cost params). */
+int gmpc_bilevel_grad(gmpc_ctx* ctx, int B, int loss_kind, const float* desired,
+                      const float* critic, float sign, float* loss, float* grad_sum, void* stream);
+
+/* a14-a15: critic BCE loss and gradient (gan/js_policy.py:41-58, critic/nn.py:28-42).
+ *   xseq [Bc][T+1][n], label [Bc] (+1 / -1), critic params
+ *   -> loss_sum [1] (SUM over the batch of -log p), grad_sum [critic_count] (SUM over the batch). */
+int gmpc_critic_loss_grad(gmpc_ctx* ctx, int Bc, const float* xseq, const float* label,
+                          const float* critic, float* loss_sum, float* grad_sum, void* stream);
+
+/* a14/a16: critic scores and (optionally) d score / d xseq.
+ *   -> score [Bc]; dxseq [Bc][T+1][n] or NULL. */
+int gmpc_critic_score_vjp(gmpc_ctx* ctx, int Bc, const float* xseq, const float* critic,
+                          float* score, float* dxseq, void* stream);
+
+/* a18: optax.chain(clip_by_global_norm(max_norm), adam(lr)) on one contiguous trainable range
+ * (gan/runner.py:51-63).  grad is scaled by grad_scale first (1/B for a batch sum).
+ * step = 1-based update count.  params, m, v [count] are updated in place. */
+int gmpc_adam_clip_step(gmpc_ctx* ctx, long count, float* params, const float* grad, float* m,
+                        float* v, float grad_scale, int step, float lr, float max_norm, float b1,
+                        float b2, float eps, void* stream);
+
+/* Device pointers into the ctx's solution of the last gmpc_ilqr_solve / gmpc_bilevel_grad (valid
+ * until the next such call): 0 X, 1 U, 2 H = A^-1 B, 3 dX, 4 Bvec, 5 AB, 6 K, 7 k.
+ * Used by the parity tests and by EvalMPC.get_optimal_values' `lqr` slot. */
+const float* gmpc_debug_buffer(gmpc_ctx* ctx, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,95 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/gan_mpc_amd.h declares,
+fails loudly without a GPU, and the flax-tree <-> flat packing round-trips."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import gan_mpc_oracle as orc
+from gan_mpc_amd import _lib, params as P
+from gan_mpc_amd.engine import make_shape
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _lib_or_skip():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libgan_mpc_amd.so not built (run __graft_entry__.build())")
+    return _lib.load()
+
+
+def test_header_symbols_are_exported_and_bound():
+    lib = _lib_or_skip()
+    hdr = open(os.path.join(ROOT, "include", "gan_mpc_amd.h")).read()
+    declared = set(re.findall(r"\b(gmpc_[a-z_]+)\s*\(", hdr))
+    assert len(declared) >= 14
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == declared
+
+
+def test_param_counts_match_survey():
+    lib = _lib_or_skip()
+    s = make_shape(17, 6, 50, [23, 200, 200, 200, 17], [17, 128, 128, 10], 64, [64, 1])
+    # 88,617 dynamics / 20,106 cost / 21,057 critic parameters at C2
+    assert [lib.gmpc_param_count(C.byref(s), i) for i in range(3)] == [88617, 20106, 21057]
+    s = make_shape(17, 6, 50, [23, 200, 200, 200, 17], [17, 128, 128, 10], 64, [64, 256, 256, 256, 1])
+    assert lib.gmpc_param_count(C.byref(s), 2) == 169473
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a GPU")
+def test_no_gpu_fails_loudly():
+    lib = _lib_or_skip()
+    s = make_shape(3, 1, 5, [4, 8, 3], [3, 8, 2])
+    ctx = C.c_void_p()
+    rc = lib.gmpc_create(C.byref(s), 4, 0, C.byref(ctx))
+    assert rc == -2 and b"no CPU fallback" in lib.gmpc_last_error()
+    from gan_mpc_amd.engine import Engine
+    with pytest.raises(_lib.GmpcError):
+        Engine(3, 1, 5, [4, 8, 3], [3, 8, 2], max_batch=4)
+
+
+def test_bad_shape_rejected_without_gpu_work():
+    lib = _lib_or_skip()
+    s = make_shape(376, 17, 50, [393, 200, 376], [376, 128, 10])
+    ctx = C.c_void_p()
+    assert lib.gmpc_create(C.byref(s), 4, 0, C.byref(ctx)) == -1
+    assert b"unsupported shape" in lib.gmpc_last_error()
+
+
+def test_mlp_pack_roundtrip():
+    pb = orc.make_problem(5, 2, 4, 3, seed=1, dyn_hidden=(7, 9), cost_hidden=(6,), cost_fout=4,
+                          bias_scale=0.5)
+    tree = P.layers_to_tree(pb["dyn"])
+    flat = P.pack_mlp(tree)
+    assert flat.size == sum(W.size + b.size for W, b in pb["dyn"])
+    assert P.mlp_dims(tree) == [7, 7, 9, 5]
+    back = P.tree_to_layers(P.unpack_mlp(flat, P.mlp_dims(tree)))
+    for (W, b), (W2, b2) in zip(pb["dyn"], back):
+        np.testing.assert_array_equal(W, W2)
+        np.testing.assert_array_equal(b, b2)
+    # kernel (in,out) row-major then bias
+    np.testing.assert_array_equal(flat[:49].reshape(7, 7), pb["dyn"][0][0])
+    np.testing.assert_array_equal(flat[49:56], pb["dyn"][0][1])
+
+
+def test_critic_pack_roundtrip_and_gate_order():
+    pb = orc.make_problem(5, 2, 4, 3, seed=2, lstm_features=8, head_hidden=(6,), bias_scale=0.5)
+    tree = P.critic_oracle_to_tree(pb["critic"])
+    cell = tree["params"][P.LSTM_SCOPE]
+    assert set(cell) == {"ii", "if", "ig", "io", "hi", "hf", "hg", "ho"}
+    assert "bias" not in cell["ii"] and "bias" in cell["hi"]
+    flat = P.pack_critic(tree)
+    n, F, head = P.critic_dims(tree)
+    assert (n, F, head) == (5, 8, [8, 6, 1])
+    back = P.critic_tree_to_oracle(P.unpack_critic(flat, n, F, head))
+    for k in ("Wx", "Wh", "b"):
+        np.testing.assert_array_equal(back[k], pb["critic"][k])
+    # forget-gate block sits second: columns F..2F of Wx
+    np.testing.assert_array_equal(flat[: n * 4 * F].reshape(n, 4 * F)[:, F:2 * F],
+                                  cell["if"]["kernel"])

@@ -1,0 +1,226 @@
+"""GPU parity: every C-ABI entry point against the oracle on the same seeded inputs.
+
+The bar (BASELINE.json north_star): 1e-5 relative fp32.  The fp64 oracle is the arbiter; where a
+chained fp32 computation cannot itself reach 1e-5 (the oracle's own fp32 run shows that), HIP must
+be no worse than 4x the oracle's fp32 error (see gpu_util.assert_parity)."""
+
+import numpy as np
+import pytest
+import torch
+
+import gan_mpc_oracle as orc
+import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {
+    # name: (n, m, T, B, kwargs)
+    "tiny-ragged": (5, 2, 8, 7, dict(dyn_hidden=(33, 47), cost_hidden=(24,), cost_fout=6)),
+    "c1-pendulum": (3, 1, 20, 32, {}),
+    "c2-cheetah": (17, 6, 50, 48, {}),
+    "trained-like": (17, 6, 50, 32, dict(out_scale=0.1)),
+    "wide": (40, 9, 6, 5, dict(dyn_hidden=(256, 64), cost_hidden=(256, 100), cost_fout=32)),
+}
+
+
+def _setup(name, critic=False, **over):
+    n, m, T, B, kw = SHAPES[name]
+    kw = dict(kw)
+    kw.update(over)
+    pb = gu.problem(n, m, T, B, seed=11, **kw)
+    pb64 = orc.cast_problem(pb, np.float64)
+    eng = gu.engine_for(pb, critic=critic)
+    return pb, pb64, eng
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_rollout_cost(name):
+    pb, pb64, eng = _setup(name)
+    d = eng.to_dev
+    X, costs = eng.rollout_cost(d(pb["x0"]), d(pb["U"]), d(pb["goal"]))
+    X32 = orc.rollout(pb["dyn"], pb["U"], pb["x0"])
+    X64 = orc.rollout(pb64["dyn"], pb64["U"], pb64["x0"])
+    gu.assert_parity("X", X.cpu().numpy(), X32, X64)
+    c32 = orc.evaluate(pb["cmlp"], pb["mpc_w"], pb["goal"], X32, pb["U"])
+    c64 = orc.evaluate(pb64["cmlp"], pb64["mpc_w"], pb64["goal"], X64, pb64["U"])
+    gu.assert_parity("costs", costs.cpu().numpy(), c32, c64)
+
+
+def test_rollout_batch_not_multiple_of_block():
+    """ragged batch: B = 1 and B = 5 (workgroups own 4 trajectories)."""
+    pb, pb64, eng = _setup("tiny-ragged")
+    d = eng.to_dev
+    X64 = orc.rollout(pb64["dyn"], pb64["U"], pb64["x0"])
+    for B in (1, 5):
+        X, _ = eng.rollout_cost(d(pb["x0"][:B]), d(pb["U"][:B]), d(pb["goal"][:B]))
+        assert gu.rel_err(X.cpu().numpy(), X64[:B]) < 1e-5
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+@pytest.mark.parametrize("after_rollout", [False, True])
+def test_lqr_backward(name, after_rollout):
+    pb, pb64, eng = _setup(name)
+    d = eng.to_dev
+    T = pb["T"]
+    if after_rollout:
+        Xd, _ = eng.rollout_cost(d(pb["x0"]), d(pb["U"]), d(pb["goal"]))
+        X = Xd.cpu().numpy()
+    else:
+        X = orc.rollout(pb["dyn"], pb["U"], pb["x0"])
+        Xd = d(X)
+    out = eng.lqr_backward(Xd, d(pb["U"]), d(pb["goal"]), after_rollout=after_rollout)
+    # both oracles linearise at the SAME trajectory the kernel saw
+    X64 = X.astype(np.float64)
+    lqr32 = orc.get_lqr_params(pb["dyn"], pb["cmlp"], pb["mpc_w"], pb["goal"], X, pb["U"])
+    lqr64 = orc.get_lqr_params(pb64["dyn"], pb64["cmlp"], pb64["mpc_w"], pb64["goal"], X64, pb64["U"])
+    B, n, m = pb["B"], pb["n"], pb["m"]
+    q = np.concatenate([X64[:, :T], pb64["U"]], -1).reshape(B * T, n + m)
+    bad_s = gu.near_kink(pb64["dyn"], q).reshape(B, T)
+    bad_s[:, -1] |= gu.near_kink(pb64["cmlp"], X64[:, T])
+    ok_b = ~bad_s.any(axis=1)
+    assert ok_b.sum() >= B // 2, "too many trajectories near a relu kink; change the seed"
+    AB = out["AB"].cpu().numpy()
+    AB32 = np.concatenate([lqr32[5][:, :T], lqr32[6][:, :T]], -1)
+    AB64 = np.concatenate([lqr64[5][:, :T], lqr64[6][:, :T]], -1)
+    ok_s = ~bad_s
+    gu.assert_parity("AB", AB[ok_s], AB32[ok_s], AB64[ok_s])
+    K32, k32, _, _ = orc.tvlqr(*lqr32)
+    K64, k64, _, _ = orc.tvlqr(*lqr64)
+    g32, a32 = orc.adjoint(lqr32[5], lqr32[6], lqr32[1], lqr32[3])
+    g64, a64 = orc.adjoint(lqr64[5], lqr64[6], lqr64[1], lqr64[3])
+    gu.assert_parity("grad", out["grad"].cpu().numpy()[ok_b], g32[ok_b], g64[ok_b])
+    gu.assert_parity("adjoints", out["adjoints"].cpu().numpy()[ok_b], a32[ok_b], a64[ok_b])
+    gu.assert_parity("K", out["K"].cpu().numpy()[ok_b], K32[ok_b], K64[ok_b])
+    gu.assert_parity("k", out["k"].cpu().numpy()[ok_b], k32[ok_b], k64[ok_b])
+
+
+@pytest.mark.parametrize("name,head", [("tiny-ragged", (12,)), ("c2-cheetah", ()),
+                                       ("c2-cheetah", (256, 256, 256))])
+def test_critic_loss_grad(name, head):
+    pb, pb64, eng = _setup(name, critic=True, head_hidden=head)
+    d = eng.to_dev
+    B = pb["B"]
+    rng = np.random.default_rng(5)
+    xseq = np.concatenate([pb["true_seq"], pb["goal"]], 0)          # 2B sequences
+    label = np.concatenate([np.ones(B), -np.ones(B)]).astype(np.float32)
+    perm = rng.permutation(2 * B)
+    xseq, label = xseq[perm], label[perm]
+    ls, gs = eng.critic_loss_grad(d(xseq), d(label), d(gu.critic_flat(pb)))
+    l32, g32 = orc.critic_loss_and_grad(pb["critic"], xseq, label)
+    l64, g64 = orc.critic_loss_and_grad(pb64["critic"], xseq.astype(np.float64), label.astype(np.float64))
+    gu.assert_parity("critic loss", ls.cpu().numpy() / (2 * B), l32, l64)
+    gu.assert_parity("critic grad", gs.cpu().numpy() / (2 * B), gu.pack_grads_critic(g32),
+                     gu.pack_grads_critic(g64))
+
+
+def test_critic_score_vjp():
+    pb, pb64, eng = _setup("c2-cheetah", critic=True)
+    d = eng.to_dev
+    xs = pb["true_seq"]
+    score, dx = eng.critic_score_vjp(d(xs), d(gu.critic_flat(pb)))
+    s32 = orc.critic_forward(pb["critic"], xs)
+    s64 = orc.critic_forward(pb64["critic"], xs.astype(np.float64))
+    gu.assert_parity("score", score.cpu().numpy(), s32, s64)
+    # generator_loss_grad_x is d(-score)/dx
+    gu.assert_parity("dscore/dx", -dx.cpu().numpy(), orc.generator_loss_grad_x(pb["critic"], xs),
+                     orc.generator_loss_grad_x(pb64["critic"], xs.astype(np.float64)))
+
+
+def test_adam_clip_step():
+    pb, _, eng = _setup("tiny-ragged")
+    rng = np.random.default_rng(2)
+    cnt = 20109
+    p = rng.standard_normal(cnt).astype(np.float32)
+    m = np.zeros(cnt, np.float32)
+    v = np.zeros(cnt, np.float32)
+    pd, md, vd = eng.to_dev(p), eng.to_dev(m), eng.to_dev(v)
+    p64, m64, v64 = p.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    for step in range(1, 4):
+        # step 2 has a huge gradient so the global-norm clip is active
+        g = (rng.standard_normal(cnt) * (1e3 if step == 2 else 1.0)).astype(np.float32)
+        eng.adam_clip_step(pd, eng.to_dev(g), md, vd, step, lr=1e-3, grad_scale=0.5)
+        p, m, v = orc.adam_clip_step(p, 0.5 * g, m, v, step, 1e-3)
+        p64, m64, v64 = orc.adam_clip_step(p64, 0.5 * g.astype(np.float64), m64, v64, step, 1e-3)
+        gu.assert_parity(f"adam p step {step}", pd.cpu().numpy(), p, p64)
+        gu.assert_parity(f"adam m step {step}", md.cpu().numpy(), m, m64)
+        gu.assert_parity(f"adam v step {step}", vd.cpu().numpy(), v, v64)
+
+
+@pytest.mark.parametrize("name", ["tiny-ragged", "trained-like"])
+def test_ilqr_single_iteration_teacher_forced(name):
+    """maxiter=1 from the same start: tvlqr + line search + re-linearisation, one iteration."""
+    pb, pb64, eng = _setup(name)
+    d = eng.to_dev
+    kw = {"maxiter": 1}
+    out = eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]), kw)
+    r32 = orc.ilqr(pb["dyn"], pb["cmlp"], pb["mpc_w"], pb["goal"], pb["x0"], pb["U"], kw)
+    r64 = orc.ilqr(pb64["dyn"], pb64["cmlp"], pb64["mpc_w"], pb64["goal"], pb64["x0"], pb64["U"], kw)
+    it = out["iterations"].cpu().numpy()
+    np.testing.assert_array_equal(it, r64[6])
+    # trajectories whose accepted step size agrees between fp32 and fp64 oracles (a line-search
+    # branch decided by the last bit is not a parity failure)
+    same = np.isclose(r32[2], r64[2], rtol=1e-3)
+    assert same.mean() > 0.7
+    gu.assert_parity("U", out["U"].cpu().numpy()[same], r32[1][same], r64[1][same], tol=1e-4)
+    gu.assert_parity("X", out["X"].cpu().numpy()[same], r32[0][same], r64[0][same], tol=1e-4)
+    gu.assert_parity("obj", out["obj"].cpu().numpy()[same], r32[2][same], r64[2][same], tol=1e-4)
+
+
+def test_ilqr_converges_on_lq_problem():
+    """KAT: linear dynamics (zero hidden->out weights except a linear path is impossible with relu, so
+    use zero dynamics weights: x' = x) and the smooth-L2 cost: iLQR must reduce the objective and
+    stop; HIP and oracle agree on the optimum."""
+    pb, pb64, eng = _setup("tiny-ragged", out_scale=0.05)
+    d = eng.to_dev
+    out = eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]))
+    obj0 = orc.objective(pb64["dyn"], pb64["cmlp"], pb64["mpc_w"], pb64["goal"], pb64["U"], pb64["x0"])
+    r64 = orc.ilqr(pb64["dyn"], pb64["cmlp"], pb64["mpc_w"], pb64["goal"], pb64["x0"], pb64["U"])
+    obj = out["obj"].cpu().numpy()
+    assert (obj <= obj0 + 1e-6).all()
+    # both reached (nearly) the same local optimum value
+    assert np.median(np.abs(obj - r64[2]) / np.abs(r64[2])) < 1e-3
+    # the returned X is the rollout of the returned U, the objective is its cost
+    X64 = orc.rollout(pb64["dyn"], out["U"].cpu().numpy().astype(np.float64), pb64["x0"])
+    assert gu.rel_err(out["X"].cpu().numpy(), X64) < 1e-5
+    c64 = orc.evaluate(pb64["cmlp"], pb64["mpc_w"], pb64["goal"], X64,
+                       out["U"].cpu().numpy().astype(np.float64)).sum(1)
+    assert gu.rel_err(obj, c64) < 1e-5
+
+
+@pytest.mark.parametrize("loss_kind", [0, 1])
+def test_bilevel_grad(loss_kind):
+    pb, pb64, eng = _setup("trained-like", critic=True)
+    d = eng.to_dev
+    B = pb["B"]
+    kw = {"maxiter": 3}
+    out = eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]), kw)
+    crit = d(gu.critic_flat(pb))
+    loss, gsum = eng.bilevel_grad(B, loss_kind, desired=d(pb["true_seq"]), critic=crit, sign=1.0)
+    # the oracle evaluates the upper level at the SAME lower-level solution
+    X = out["X"].cpu().numpy()
+    U = out["U"].cpu().numpy()
+
+    def upper(p, Xa, Ua):
+        lqr = orc.get_lqr_params(p["dyn"], p["cmlp"], p["mpc_w"], p["goal"], Xa, Ua)
+        if loss_kind == 0:
+            lv, lx = orc.l2_loss(Xa, p["true_seq"]), orc.l2_loss_grad_x(Xa, p["true_seq"])
+        else:
+            lv, lx = orc.generator_loss(p["critic"], Xa), orc.generator_loss_grad_x(p["critic"], Xa)
+        Bv = orc.loss_grad_wrt_control(lqr[5], lqr[6], lx)
+        Hc, dX = orc.hessian_solve(lqr, Bv)
+        g_mpc, g_cost = orc.cost_vjp(p["cmlp"], p["mpc_w"], p["goal"], Xa, Ua, Hc, dX)
+        return lv, Hc, gu.pack_grads_cost(g_mpc.sum(0), [(a.sum(0), b.sum(0)) for a, b in g_cost])
+
+    l32, H32, g32 = upper(pb, X, U)
+    l64, H64, g64 = upper(pb64, X.astype(np.float64), U.astype(np.float64))
+    gu.assert_parity("loss", loss.cpu().numpy(), l32, l64)
+    Hd = eng.debug_buffer(2, (B, pb["T"], pb["m"])).cpu().numpy()
+    gu.assert_parity("H = A^-1 B", Hd, H32, H64, tol=1e-4)
+    gu.assert_parity("bilevel grad", gsum.cpu().numpy(), g32, g64, tol=1e-4)
+
+
+def test_unsupported_shape_fails_loudly():
+    from gan_mpc_amd import GmpcError
+    from gan_mpc_amd.engine import Engine
+    with pytest.raises(GmpcError, match="unsupported shape"):
+        Engine(376, 17, 50, [393, 200, 200, 200, 376], [376, 128, 128, 10], max_batch=4)

@@ -1,0 +1,215 @@
+"""Pin the oracle's hand-derived derivatives against torch float64 autograd
+of a literal transcription of the reference formulas (tests/torch_ref.py),
+plus analytic known-answer tests."""
+
+import numpy as np
+import pytest
+import torch
+
+import gan_mpc_oracle as orc
+import torch_ref as tr
+
+
+def small_problem(seed=1, n=4, m=2, T=6, B=3, bias=0.3):
+    pb = orc.make_problem(n, m, T, B, seed=seed, dtype=np.float64,
+                          dyn_hidden=(16, 16), cost_hidden=(12,), cost_fout=5,
+                          lstm_features=8, head_hidden=(6,), bias_scale=bias)
+    return pb
+
+
+def test_dynamics_jacobian_vs_autograd():
+    pb = small_problem()
+    dyn = tr.layers64(pb["dyn"])
+    x, u = pb["x0"], pb["U"][:, 0]
+    A, Bm = orc.dynamics_jacobians(pb["dyn"], x, u)
+    for b in range(pb["B"]):
+        Ja, Jb = torch.autograd.functional.jacobian(
+            lambda xx, uu: tr.dynamics(dyn, xx, uu), (tr.t64(x[b]), tr.t64(u[b])))
+        np.testing.assert_allclose(A[b], Ja.numpy(), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(Bm[b], Jb.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_cost_quadratize_vs_autograd():
+    pb = small_problem()
+    T = pb["T"]
+    X = orc.rollout(pb["dyn"], pb["U"], pb["x0"])
+    Q, q, R, r, M = orc.cost_quadratize(pb["cmlp"], pb["mpc_w"], pb["goal"], X, pb["U"])
+    cm = tr.layers64(pb["cmlp"])
+    mw = tr.t64(pb["mpc_w"])
+    Up = orc.pad(pb["U"])
+    for b in range(pb["B"]):
+        goal = tr.t64(pb["goal"][b])
+        for t in (0, 3, T):
+            f = lambda xx, uu: tr.cost(cm, mw, goal, xx, uu, t, T)
+            xx, uu = tr.t64(X[b, t]), tr.t64(Up[b, t])
+            gx, gu = torch.autograd.functional.jacobian(f, (xx, uu))
+            (hxx, hxu), (_, huu) = torch.autograd.functional.hessian(f, (xx, uu))
+            np.testing.assert_allclose(q[b, t], gx.numpy(), rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(r[b, t], gu.numpy(), rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(Q[b, t], hxx.numpy(), rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(R[b, t], huu.numpy(), rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(M[b, t], hxu.numpy(), rtol=1e-9, atol=1e-11)
+
+
+def test_adjoint_is_objective_gradient():
+    pb = small_problem()
+    X = orc.rollout(pb["dyn"], pb["U"], pb["x0"])
+    lqr = orc.get_lqr_params(pb["dyn"], pb["cmlp"], pb["mpc_w"], pb["goal"], X, pb["U"])
+    g, lam = orc.adjoint(lqr[5], lqr[6], lqr[1], lqr[3])
+    dyn, cm = tr.layers64(pb["dyn"]), tr.layers64(pb["cmlp"])
+    for b in range(pb["B"]):
+        U = tr.t64(pb["U"][b]).requires_grad_(True)
+        J = tr.objective(dyn, cm, tr.t64(pb["mpc_w"]), tr.t64(pb["goal"][b]), U, tr.t64(pb["x0"][b]))
+        gU = torch.autograd.grad(J, U)[0]
+        np.testing.assert_allclose(g[b], gU.numpy(), rtol=1e-9, atol=1e-11)
+        np.testing.assert_allclose(
+            float(J), orc.objective(pb["dyn"], pb["cmlp"], pb["mpc_w"], pb["goal"], pb["U"], pb["x0"])[b],
+            rtol=1e-12)
+
+
+def test_tvlqr_solves_the_lq_subproblem():
+    """The gains returned by tvlqr minimise the LQ model: dU = k + K dx is the
+    Newton step -A^{-1} g of the objective (dense autograd Hessian) up to the
+    1e-8 regulariser."""
+    pb = small_problem(seed=3)
+    X = orc.rollout(pb["dyn"], pb["U"], pb["x0"])
+    lqr = orc.get_lqr_params(pb["dyn"], pb["cmlp"], pb["mpc_w"], pb["goal"], X, pb["U"])
+    K, k, P, p = orc.tvlqr(*lqr)
+    g, _ = orc.adjoint(lqr[5], lqr[6], lqr[1], lqr[3])
+    B, T, m = pb["U"].shape
+    n = pb["n"]
+    dyn, cm = tr.layers64(pb["dyn"]), tr.layers64(pb["cmlp"])
+    for b in range(B):
+        # closed-loop step on the linear model
+        dx = np.zeros(n)
+        dU = np.zeros((T, m))
+        for t in range(T):
+            dU[t] = k[b, t] + K[b, t] @ dx
+            dx = lqr[5][b, t] @ dx + lqr[6][b, t] @ dU[t]
+        Hd = torch.autograd.functional.hessian(
+            lambda Uf: tr.objective(dyn, cm, tr.t64(pb["mpc_w"]), tr.t64(pb["goal"][b]),
+                                    Uf.reshape(T, m), tr.t64(pb["x0"][b])),
+            tr.t64(pb["U"][b]).reshape(-1)).numpy()
+        newton = -np.linalg.solve(Hd, g[b].reshape(-1))
+        np.testing.assert_allclose(dU.reshape(-1), newton, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("loss", ["l2", "js"])
+def test_bilevel_structured_equals_dense_autograd(loss):
+    """policy/optimizers.py:61-71 as written (dense Hessian + LU + autograd
+    mixed derivative) equals the oracle's structured solve."""
+    pb = small_problem(seed=5)
+    X = orc.rollout(pb["dyn"], pb["U"], pb["x0"])
+    U = pb["U"]
+    lqr = orc.get_lqr_params(pb["dyn"], pb["cmlp"], pb["mpc_w"], pb["goal"], X, U)
+    if loss == "l2":
+        lx = orc.l2_loss_grad_x(X, pb["true_seq"])
+    else:
+        lx = orc.generator_loss_grad_x(pb["critic"], X)
+    Bvec = orc.loss_grad_wrt_control(lqr[5], lqr[6], lx)
+    Hc, dX = orc.hessian_solve(lqr, Bvec)
+    g_mpc, g_cost = orc.cost_vjp(pb["cmlp"], pb["mpc_w"], pb["goal"], X, U, Hc, dX)
+    dyn, cm = tr.layers64(pb["dyn"]), tr.layers64(pb["cmlp"])
+    cr = tr.critic64(pb["critic"])
+    for b in range(pb["B"]):
+        des = tr.t64(pb["true_seq"][b])
+        lf = (lambda XX: tr.l2_loss(XX, des)) if loss == "l2" else (lambda XX: tr.generator_loss(cr, XX))
+        Bv, A, H, grads = tr.bilevel_dense(
+            dyn, cm, tr.t64(pb["mpc_w"]), tr.t64(pb["goal"][b]), tr.t64(pb["x0"][b]),
+            tr.t64(U[b]), lf)
+        np.testing.assert_allclose(Bvec[b].reshape(-1), Bv.numpy(), rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(Hc[b].reshape(-1), H.numpy(), rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(g_mpc[b], grads[0].numpy(), rtol=1e-6, atol=1e-9)
+        for li, (gW, gb) in enumerate(g_cost):
+            np.testing.assert_allclose(gW[b], grads[1 + 2 * li].numpy(), rtol=1e-6, atol=1e-9)
+            gbt = grads[2 + 2 * li]
+            gbt = np.zeros_like(gb[b]) if gbt is None else gbt.numpy()
+            np.testing.assert_allclose(gb[b], gbt, rtol=1e-6, atol=1e-9)
+
+
+def test_critic_loss_and_grad_vs_autograd():
+    pb = small_problem(seed=7)
+    B = pb["B"]
+    xseq = pb["true_seq"]
+    label = np.array([1.0, -1.0, 1.0])
+    loss, grads = orc.critic_loss_and_grad(pb["critic"], xseq, label)
+    cr = tr.critic64(pb["critic"])
+    leaves = [cr["Wx"], cr["Wh"], cr["b"]] + [t for Wb in cr["head"] for t in Wb]
+    for t in leaves:
+        t.requires_grad_(True)
+    tot = 0.0
+    for b in range(B):
+        s = tr.lstm_critic(cr, tr.t64(xseq[b]))
+        p = torch.sigmoid(s)
+        p = p if label[b] > 0 else 1 - p
+        tot = tot + (-torch.log(p)).sum()
+    tot = tot / B
+    gs = torch.autograd.grad(tot, leaves)
+    np.testing.assert_allclose(loss, float(tot), rtol=1e-12)
+    np.testing.assert_allclose(grads["Wx"], gs[0].numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(grads["Wh"], gs[1].numpy(), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(grads["b"], gs[2].numpy(), rtol=1e-9, atol=1e-12)
+    for li, (gW, gb) in enumerate(grads["head"]):
+        np.testing.assert_allclose(gW, gs[3 + 2 * li].numpy(), rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(gb, gs[4 + 2 * li].numpy(), rtol=1e-9, atol=1e-12)
+
+
+def test_generator_loss_grad_x_vs_autograd():
+    pb = small_problem(seed=8)
+    X = pb["true_seq"]
+    dx = orc.generator_loss_grad_x(pb["critic"], X)
+    cr = tr.critic64(pb["critic"])
+    for b in range(pb["B"]):
+        xs = tr.t64(X[b]).requires_grad_(True)
+        g = torch.autograd.grad(tr.generator_loss(cr, xs), xs)[0]
+        np.testing.assert_allclose(dx[b], g.numpy(), rtol=1e-8, atol=1e-11)
+    # generator_loss == -score (js_policy.py:66-68: -log s(x) + log(1-s(x)) = -x)
+    np.testing.assert_allclose(orc.generator_loss(pb["critic"], X),
+                               -orc.critic_forward(pb["critic"], X), rtol=1e-9, atol=1e-12)
+
+
+# ---------------- analytic known-answer tests ----------------------------
+def test_kat_zero_control_has_zero_action_cost():
+    w = np.array([0.3, 0.0])
+    x = np.zeros((1, 3)); g = np.zeros((1, 3))
+    assert orc.stage_cost(x, np.zeros((1, 2)), g, w)[0] == 0.0
+
+
+def test_kat_critic_loss_at_zero_score_is_ln2():
+    pb = small_problem()
+    cr = dict(pb["critic"])
+    cr["head"] = [(np.zeros_like(W), np.zeros_like(b)) for W, b in cr["head"]]
+    loss, _ = orc.critic_loss_and_grad(cr, pb["true_seq"], np.array([1.0, -1.0, 1.0]))
+    np.testing.assert_allclose(loss, np.log(2.0), rtol=1e-14)
+
+
+def test_kat_zero_weight_dynamics_is_identity():
+    pb = small_problem(bias=0.0)
+    dyn = [(np.zeros_like(W), np.zeros_like(b)) for W, b in pb["dyn"]]
+    x1, _ = orc.dynamics_predict(dyn, pb["x0"], pb["U"][:, 0])
+    np.testing.assert_array_equal(x1, pb["x0"])
+    A, Bm = orc.dynamics_jacobians(dyn, pb["x0"], pb["U"][:, 0])
+    np.testing.assert_array_equal(A, np.broadcast_to(np.eye(pb["n"]), A.shape))
+    assert not Bm.any()
+
+
+def test_kat_adam_first_step_is_minus_lr_sign():
+    p = np.zeros(5); g = np.array([1.0, -2.0, 3.0, -4.0, 0.5])
+    p1, m, v = orc.adam_clip_step(p, g, np.zeros(5), np.zeros(5), 1, 1e-3)
+    np.testing.assert_allclose(p1, -1e-3 * np.sign(g), rtol=1e-6)
+
+
+def test_kat_clip_by_global_norm():
+    g = np.full(4, 100.0)  # norm 200 -> scaled to 100
+    _, m, _ = orc.adam_clip_step(np.zeros(4), g, np.zeros(4), np.zeros(4), 1, 1e-3)
+    np.testing.assert_allclose(m, 0.1 * 50.0 * np.ones(4), rtol=1e-12)
+
+
+def test_kat_cholesky_nan_on_indefinite():
+    L = orc.cholesky_lower(np.array([[[1.0, 2.0], [2.0, 1.0]]]))
+    assert np.isnan(L).any()
+    G = np.array([[[4.0, 1.0], [1.0, 3.0]]])
+    L = orc.cholesky_lower(G)
+    np.testing.assert_allclose(L @ np.swapaxes(L, -1, -2), G, rtol=1e-14)
+    x = orc.cho_solve(L, np.array([[[1.0], [2.0]]]))
+    np.testing.assert_allclose(G @ x, [[[1.0], [2.0]]], rtol=1e-13)
