@@ -31,8 +31,8 @@ void gmpc_launch_lstm_bwd(int, const CriticDesc&, const float*, const float*, co
 void gmpc_launch_wgrad(int, int, int, const float*, int, const float*, int, float*, float*, int,
                        float*, int, hipStream_t);
 void gmpc_launch_sum(int, const float*, float*, int, hipStream_t);
-void gmpc_launch_adam(long, float*, const float*, float*, float*, float, int, float, float, float,
-                      float, float, float*, hipStream_t);
+void gmpc_launch_adam(long, float*, const float*, float*, float*, float, int, double, double, double,
+                      double, double, float*, hipStream_t);
 void gmpc_launch_l2loss(int, int, int, const float*, const float*, float*, float*, hipStream_t);
 void gmpc_launch_bvec(int, int, int, int, const float*, const float*, float*, hipStream_t);
 void gmpc_launch_costvjp(int, int, int, int, const MlpDesc&, const float*, float, const float*,
@@ -543,8 +543,8 @@ extern "C" int gmpc_bilevel_grad(gmpc_ctx* c, int B, int loss_kind, const float*
 }
 
 extern "C" int gmpc_adam_clip_step(gmpc_ctx* c, long count, float* params, const float* grad,
-                                   float* m, float* v, float grad_scale, int step, float lr,
-                                   float max_norm, float b1, float b2, float eps, void* stream) {
+                                   float* m, float* v, float grad_scale, int step, double lr,
+                                   double max_norm, double b1, double b2, double eps, void* stream) {
   if (!c || !params || !grad || !m || !v) return fail(GMPC_EINVAL, "null argument");
   if (count < 1 || step < 1) return fail(GMPC_EINVAL, "count and step must be positive");
   HIP_TRY(hipSetDevice(c->device));
@@ -562,6 +562,8 @@ extern "C" const float* gmpc_debug_buffer(gmpc_ctx* c, int which) {
   switch (which) {
     case 0: return c->Xs; case 1: return c->Us; case 2: return c->Hout; case 3: return c->dX;
     case 4: return c->Bvec; case 5: return c->AB; case 6: return c->Ks; case 7: return c->ks;
+    case 12: return c->Xc; case 13: return c->Uc;
+    case 8: return c->alpha; case 9: return c->obj_step; case 10: return c->U_step;
     default: return nullptr;
   }
 }

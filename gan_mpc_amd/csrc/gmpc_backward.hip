@@ -92,8 +92,9 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_linearize(int B, int T, int n,
       const int sp = r / n, i = r - sp * n;
       const int s = s0 + sp;
       if (s < NSamp) {
-        const float4 v = out[c * R4 + (r >> 2)];
-        AB[((size_t)s * n + i) * nm + c] = f4get(v, r & 3) + (c == i ? 1.0f : 0.0f);
+        // float view of out[c*R4 + r/4].(r%4): never select a float4 component by a run-time index
+        AB[((size_t)s * n + i) * nm + c] =
+            reinterpret_cast<const float*>(out)[c * 4 * R4 + r] + (c == i ? 1.0f : 0.0f);
       }
     }
     __syncthreads();

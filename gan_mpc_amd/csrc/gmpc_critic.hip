@@ -374,15 +374,15 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_sqsum_part(long count, const f
 // optax clip_by_global_norm + adam (gan/runner.py:58): g <- g*scale; if !(norm < max_norm)
 // g <- g / norm * max_norm; m,v update; p += -lr * mhat / (sqrt(vhat) + eps)
 __global__ void k_adam(long count, float* p, const float* g, float* m, float* v, float scale,
-                       const float* sqsum, float max_norm, float lr, float b1, float b2, float eps,
-                       float bc1, float bc2) {
+                       const float* sqsum, float max_norm, float lr, float b1, float b2, float omb1,
+                       float omb2, float eps, float bc1, float bc2) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= count) return;
   const float gn = sqrtf(sqsum[0]);
   float x = g[e] * scale;
   if (!(gn < max_norm)) x = x / gn * max_norm;
-  const float mn = b1 * m[e] + (1.f - b1) * x;
-  const float vn = b2 * v[e] + (1.f - b2) * x * x;
+  const float mn = b1 * m[e] + omb1 * x;
+  const float vn = b2 * v[e] + omb2 * x * x;
   m[e] = mn;
   v[e] = vn;
   const float mh = mn / bc1, vh = vn / bc2;
@@ -455,12 +455,13 @@ void gmpc_launch_sum(int count, const float* v, float* out, int square, hipStrea
 }
 
 void gmpc_launch_adam(long count, float* p, const float* g, float* m, float* v, float scale,
-                      int step, float lr, float max_norm, float b1, float b2, float eps,
+                      int step, double lr, double max_norm, double b1, double b2, double eps,
                       float* scratch /* >= 257 floats */, hipStream_t s) {
   const int nb = 256;
   hipLaunchKernelGGL(k_sqsum_part, dim3(nb), dim3(GMPC_THREADS), 0, s, count, g, scale, scratch + 1);
   hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, nb, scratch + 1, scratch, 0);
-  const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  const float bc1 = (float)(1.0 - pow(b1, (double)step)), bc2 = (float)(1.0 - pow(b2, (double)step));
   hipLaunchKernelGGL(k_adam, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, count, p, g, m, v,
-                     scale, scratch, max_norm, lr, b1, b2, eps, bc1, bc2);
+                     scale, scratch, (float)max_norm, (float)lr, (float)b1, (float)b2,
+                     (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, bc1, bc2);
 }

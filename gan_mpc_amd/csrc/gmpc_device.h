@@ -103,6 +103,8 @@ __device__ __forceinline__ void dense_small(const float* __restrict__ W, int K, 
   __syncthreads();
 }
 
+// f4get / f4set: ONLY with a compile-time c (fully unrolled loops) on register values.  For a
+// run-time component of an LDS float4 index the float view instead (see the note in k_traj).
 __device__ __forceinline__ float f4get(const float4& v, int c) {
   return c == 0 ? v.x : c == 1 ? v.y : c == 2 ? v.z : v.w;
 }

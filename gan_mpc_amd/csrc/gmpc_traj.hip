@@ -13,23 +13,26 @@
 
 
 // One hidden layer for the 4 trajectories of the block: z = act_in . W + b; mask bits; relu.
+// mbase points at mask word 0 of (trajectory 0, this step, this layer); trajectory c sits
+// c*mstride words further; bit c of wbits enables the mask store of trajectory c.
 __device__ __forceinline__ void hidden_layer(const float* W, const float* bias, int K, int N,
-                                             const float4* actIn, float4* actOut, uint32_t* mrow[4],
-                                             bool wmask[4]) {
+                                             const float4* actIn, float4* actOut, uint32_t* mbase,
+                                             size_t mstride, unsigned wbits) {
   const int j = threadIdx.x;
   const bool valid = j < N;
   const float bj = valid ? bias[j] : 0.f;
   float4 acc[1] = {make_float4(bj, bj, bj, bj)};
   dense_rows<1>(W, K, N, j, actIn, acc);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const bool pos = valid && f4get(acc[0], c) > 0.f;
-    const unsigned long long bal = __ballot(pos);
-    if (lane == 0 && wmask[c] && mrow[c] != nullptr) {
-      mrow[c][2 * wave] = (uint32_t)bal;
-      mrow[c][2 * wave + 1] = (uint32_t)(bal >> 32);
-    }
+  const unsigned long long b0 = __ballot(valid && acc[0].x > 0.f);
+  const unsigned long long b1 = __ballot(valid && acc[0].y > 0.f);
+  const unsigned long long b2 = __ballot(valid && acc[0].z > 0.f);
+  const unsigned long long b3 = __ballot(valid && acc[0].w > 0.f);
+  if (lane == 0 && mbase != nullptr) {
+    if (wbits & 1u) { mbase[2 * wave] = (uint32_t)b0; mbase[2 * wave + 1] = (uint32_t)(b0 >> 32); }
+    if (wbits & 2u) { mbase[mstride + 2 * wave] = (uint32_t)b1; mbase[mstride + 2 * wave + 1] = (uint32_t)(b1 >> 32); }
+    if (wbits & 4u) { mbase[2 * mstride + 2 * wave] = (uint32_t)b2; mbase[2 * mstride + 2 * wave + 1] = (uint32_t)(b2 >> 32); }
+    if (wbits & 8u) { mbase[3 * mstride + 2 * wave] = (uint32_t)b3; mbase[3 * mstride + 2 * wave + 1] = (uint32_t)(b3 >> 32); }
   }
   if (valid)
     actOut[j] = make_float4(fmaxf(acc[0].x, 0.f), fmaxf(acc[0].y, 0.f), fmaxf(acc[0].z, 0.f),
@@ -49,20 +52,24 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = a.n, m = a.m, T = a.T;
   const int b0 = blockIdx.x * GMPC_TB;
-  int bi[4];
-  bool inb[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    inb[c] = (b0 + c) < a.B;
-    bi[c] = inb[c] ? (b0 + c) : (a.B - 1);  // clamp reads of the tail block
-  }
+  // Component c of an LDS float4 is always addressed as a float ([k*4 + c]) when c is a run-time
+  // value: hipcc (ROCm 7.2) lowers `c == 0 ? v.x : ...` on an LDS reference with a lane-varying c
+  // into a branch tree that gives lanes with c == 3 the .z address (seen in the ISA and on the GPU).
+  float* const xf = reinterpret_cast<float*>(xcur);
+  float* const aAf = reinterpret_cast<float*>(actA);
+  const float* const pf = reinterpret_cast<const float*>(part);
+  // trajectory c of this block (reads of the tail block are clamped); no private arrays: a
+  // dynamically indexed register array would live in scratch
+  auto BI = [&](int c) -> int { const int b = b0 + c; return b < a.B ? b : a.B - 1; };
+  auto INB = [&](int c) -> bool { return (b0 + c) < a.B; };
   const int Lh = a.dyn.L - 1;
+  const size_t mstride = (size_t)T * Lh * GMPC_MW;   // mask words per trajectory
   const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]), w2 = sigmoidf_(a.mpc_w[2]);
 
   if (LS) {
     if (tid < GMPC_TB) {
-      const int b = bi[tid];
-      const bool act = inb[tid] && (a.active == nullptr || a.active[b] != 0);
+      const int b = BI(tid);
+      const bool act = INB(tid) && (a.active == nullptr || a.active[b] != 0);
       float o = a.obj[b];
       if (isnan(o)) o = INFINITY;
       s_objold[tid] = o;
@@ -80,20 +87,21 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
 
   while (true) {
     if (LS && !s_any) break;
-    bool wm[4];
+    // bit c set: trajectory c writes its outputs in this pass
+    unsigned wbits = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) wm[c] = LS ? (s_run[c] != 0) : inb[c];
+    for (int c = 0; c < 4; ++c) wbits |= ((LS ? (s_run[c] != 0) : INB(c)) ? 1u : 0u) << c;
     // ---- initial state
     if (tid < n) {
       const float* xs = LS ? a.X : a.x0;
       const size_t st = LS ? (size_t)(T + 1) * n : (size_t)n;
-      float4 v = make_float4(xs[bi[0] * st + tid], xs[bi[1] * st + tid], xs[bi[2] * st + tid],
-                             xs[bi[3] * st + tid]);
+      float4 v = make_float4(xs[BI(0) * st + tid], xs[BI(1) * st + tid], xs[BI(2) * st + tid],
+                             xs[BI(3) * st + tid]);
       xcur[tid] = v;
       if (!LS) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if (inb[c]) a.X[(size_t)bi[c] * (T + 1) * n + tid] = f4get(v, c);
+          if (INB(c)) a.X[(size_t)BI(c) * (T + 1) * n + tid] = f4get(v, c);
       }
     }
     float objacc = 0.f;  // lane 0 of wave c accumulates trajectory c
@@ -104,32 +112,34 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
       if (tid < n) actA[tid] = xcur[tid];
       if (tid < GMPC_TB * m) {
         const int c = tid / m, j = tid % m;
-        const size_t ub = ((size_t)bi[c] * T + t) * m + j;
+        const int bc = BI(c);
+        const size_t ub = ((size_t)bc * T + t) * m + j;
         float u;
         if (LS) {
           const float* Kr = a.Kg + ub * n;
-          const float* Xo = a.X + ((size_t)bi[c] * (T + 1) + t) * n;
+          const float* Xo = a.X + ((size_t)bc * (T + 1) + t) * n;
           float du = s_alpha[c] * a.kg[ub];
-          for (int i = 0; i < n; ++i) du = fmaf(Kr[i], f4get(xcur[i], c) - Xo[i], du);
+          for (int i = 0; i < n; ++i) du = fmaf(Kr[i], xf[i * 4 + c] - Xo[i], du);
           u = a.Uio[ub] + du;
-          if (wm[c]) a.Uc[ub] = u;
+          if ((wbits >> c) & 1u) a.Uc[ub] = u;
         } else {
           u = a.U[ub];
         }
-        f4set(actA[n + j], c, u);
+        aAf[(n + j) * 4 + c] = u;
       }
       __syncthreads();
       // ---- stage cost of (x_t, u_t): wave c handles trajectory c
       {
         const int c = wave;
         float dd = 0.f, uu = 0.f;
-        const float* g = a.goal + ((size_t)bi[c] * (T + 1) + t) * n;
+        const int bc = BI(c);
+        const float* g = a.goal + ((size_t)bc * (T + 1) + t) * n;
         for (int i = lane; i < n; i += 64) {
-          const float d = f4get(actA[i], c) - g[i];
+          const float d = aAf[i * 4 + c] - g[i];
           dd = fmaf(d, d, dd);
         }
         for (int j = lane; j < m; j += 64) {
-          const float u = f4get(actA[n + j], c);
+          const float u = aAf[(n + j) * 4 + c];
           uu = fmaf(u, u, uu);
         }
         dd = wave_sum(dd);
@@ -137,17 +147,16 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
         const float al = GMPC_ALPHA;
         const float cst = w0 * (sqrtf(uu + al * al) - al) + w1 * (sqrtf(dd + al * al) - al);
         objacc += cst;
-        if (!LS && lane == 0 && inb[c] && a.costs) a.costs[(size_t)bi[c] * (T + 1) + t] = cst;
+        if (!LS && lane == 0 && INB(c) && a.costs) a.costs[(size_t)bc * (T + 1) + t] = cst;
       }
       // ---- hidden layers
       float4* in = actA;
       float4* out = actB;
       for (int l = 0; l < Lh; ++l) {
-        uint32_t* mrow[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          mrow[c] = (LS ? a.maskc : a.masks) + (((size_t)bi[c] * T + t) * Lh + l) * GMPC_MW;
-        hidden_layer(a.dyn.W[l], a.dyn.b[l], a.dyn.dims[l], a.dyn.dims[l + 1], in, out, mrow, wm);
+        // the tail block's clamped trajectories never write (wbits), so b0-relative addressing is safe
+        uint32_t* mbase = (LS ? a.maskc : a.masks) + (size_t)b0 * mstride + ((size_t)t * Lh + l) * GMPC_MW;
+        hidden_layer(a.dyn.W[l], a.dyn.b[l], a.dyn.dims[l], a.dyn.dims[l + 1], in, out, mbase, mstride,
+                     wbits);
         __syncthreads();
         float4* tmp = in; in = out; out = tmp;
       }
@@ -163,7 +172,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
         float* Xo = LS ? a.Xc : a.X;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if (wm[c]) Xo[((size_t)bi[c] * (T + 1) + t + 1) * n + tid] = f4get(v, c);
+          if ((wbits >> c) & 1u) Xo[((size_t)BI(c) * (T + 1) + t + 1) * n + tid] = f4get(v, c);
       }
       __syncthreads();
     }
@@ -172,11 +181,9 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
       float4* in = xcur;
       float4* out = actA;
       const int Lc = a.cost.L - 1;
-      uint32_t* nomask[4] = {nullptr, nullptr, nullptr, nullptr};
-      bool nowm[4] = {false, false, false, false};
       for (int l = 0; l < Lc; ++l) {
-        hidden_layer(a.cost.W[l], a.cost.b[l], a.cost.dims[l], a.cost.dims[l + 1], in, out, nomask,
-                     nowm);
+        hidden_layer(a.cost.W[l], a.cost.b[l], a.cost.dims[l], a.cost.dims[l + 1], in, out, nullptr, 0,
+                     0u);
         __syncthreads();
         in = out;
         out = (out == actA) ? actB : actA;
@@ -186,7 +193,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
       const int c = wave;
       float yy = 0.f;
       for (int r = lane; r < fo; r += 64) {
-        const float y = f4get(part[r], c) + a.cost.b[Lc][r];
+        const float y = pf[r * 4 + c] + a.cost.b[Lc][r];
         yy = fmaf(y, y, yy);
       }
       yy = wave_sum(yy);
@@ -194,9 +201,9 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
       objacc += cst;
       if (lane == 0) {
         if (!LS) {
-          if (inb[c]) {
-            if (a.costs) a.costs[(size_t)bi[c] * (T + 1) + T] = cst;
-            a.obj[bi[c]] = objacc;
+          if (INB(c)) {
+            if (a.costs) a.costs[(size_t)BI(c) * (T + 1) + T] = cst;
+            a.obj[BI(c)] = objacc;
           }
         } else {
           s_obj[c] = objacc;
@@ -219,8 +226,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
         if (acc) {
           s_acc[c] = 1;
           s_ever[c] = 1;
-          a.obj[bi[c]] = on;
-          a.obj_step[bi[c]] = fabsf(on - oo);
+          a.obj[BI(c)] = on;
+          a.obj_step[BI(c)] = fabsf(on - oo);
         }
         s_run[c] = ((objr >= oo) && (s_alpha[c] > a.alpha_min)) ? 1 : 0;
       }
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
     // ---- commit accepted candidates
     for (int c = 0; c < GMPC_TB; ++c) {
       if (!s_acc[c]) continue;
-      const size_t b = bi[c];
+      const size_t b = BI(c);
       float* Xd = a.X + b * (T + 1) * n;
       const float* Xs = a.Xc + b * (T + 1) * n;
       for (int e = n + tid; e < (T + 1) * n; e += blockDim.x) Xd[e] = Xs[e];
@@ -254,8 +261,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
   }
   if (LS) {
     __syncthreads();
-    if (tid < GMPC_TB && inb[tid]) {
-      const int b = bi[tid];
+    if (tid < GMPC_TB && INB(tid)) {
+      const int b = BI(tid);
       const bool act = (a.active == nullptr || a.active[b] != 0);
       if (act) {
         a.alpha[b] = s_alpha[tid];
@@ -279,18 +286,15 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_masks(int NS, int n, int m, in
   __shared__ float4 actB[GMPC_THREADS];
   const int tid = threadIdx.x;
   const int s0 = blockIdx.x * 4;
-  int si[4];
-  bool in_[4];
+  unsigned wbits = 0;
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    in_[c] = s0 + c < NS;
-    si[c] = in_[c] ? s0 + c : NS - 1;
-  }
+  for (int c = 0; c < 4; ++c) wbits |= ((s0 + c < NS) ? 1u : 0u) << c;
   if (tid < n + m) {
     float4 v;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int b = si[c] / T, t = si[c] % T;
+      const int si = (s0 + c < NS) ? s0 + c : NS - 1;
+      const int b = si / T, t = si % T;
       const float x = tid < n ? X[((size_t)b * (T + 1) + t) * n + tid]
                               : U[((size_t)b * T + t) * m + (tid - n)];
       f4set(v, c, x);
@@ -302,10 +306,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_masks(int NS, int n, int m, in
   float4* in = actA;
   float4* out = actB;
   for (int l = 0; l < Lh; ++l) {
-    uint32_t* mrow[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) mrow[c] = masks + ((size_t)si[c] * Lh + l) * GMPC_MW;
-    hidden_layer(dyn.W[l], dyn.b[l], dyn.dims[l], dyn.dims[l + 1], in, out, mrow, in_);
+    hidden_layer(dyn.W[l], dyn.b[l], dyn.dims[l], dyn.dims[l + 1], in, out,
+                 masks + ((size_t)s0 * Lh + l) * GMPC_MW, (size_t)Lh * GMPC_MW, wbits);
     __syncthreads();
     float4* tmp = in; in = out; out = tmp;
   }

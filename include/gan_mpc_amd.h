@@ -140,10 +140,12 @@ int gmpc_critic_score_vjp(gmpc_ctx* ctx, int Bc, const float* xseq, const float*
 
 /* a18: optax.chain(clip_by_global_norm(max_norm), adam(lr)) on one contiguous trainable range
  * (gan/runner.py:51-63).  grad is scaled by grad_scale first (1/B for a batch sum).
- * step = 1-based update count.  params, m, v [count] are updated in place. */
+ * step = 1-based update count.  params, m, v [count] are updated in place.  The hyper-parameters
+ * are doubles: 1-b1, 1-b2 and the bias corrections are formed in double and rounded once to fp32,
+ * as optax does with its Python-float hyper-parameters. */
 int gmpc_adam_clip_step(gmpc_ctx* ctx, long count, float* params, const float* grad, float* m,
-                        float* v, float grad_scale, int step, float lr, float max_norm, float b1,
-                        float b2, float eps, void* stream);
+                        float* v, float grad_scale, int step, double lr, double max_norm, double b1,
+                        double b2, double eps, void* stream);
 
 /* Device pointers into the ctx's solution of the last gmpc_ilqr_solve / gmpc_bilevel_grad (valid
  * until the next such call): 0 X, 1 U, 2 H = A^-1 B, 3 dX, 4 Bvec, 5 AB, 6 K, 7 k.

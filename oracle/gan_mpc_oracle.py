@@ -626,6 +626,27 @@ def hessian_solve(lqr, Bvec):
     return H_out, dX
 
 
+def hessian_apply(lqr, V):
+    """(d^2 J / dU^2) V for V (B,T,m), through the LQ structure: tangent roll dx from dU = V, then
+    the adjoint of the quadratic model.  Used to check a solve by its residual A H - B."""
+    Q, _, R, _, M, A, Bm = lqr
+    Bsz, T1, n, _ = Q.shape
+    T = T1 - 1
+    dx = np.zeros((Bsz, T + 1, n), Q.dtype)
+    for t in range(T):
+        dx[:, t + 1] = np.einsum("bij,bj->bi", A[:, t], dx[:, t]) + np.einsum(
+            "bnm,bm->bn", Bm[:, t], V[:, t])
+    out = np.zeros_like(V)
+    lam = np.einsum("bij,bj->bi", Q[:, T], dx[:, T])
+    for t in range(T - 1, -1, -1):
+        out[:, t] = (np.einsum("bij,bj->bi", R[:, t], V[:, t])
+                     + np.einsum("bnm,bn->bm", M[:, t], dx[:, t])
+                     + np.einsum("bnm,bn->bm", Bm[:, t], lam))
+        lam = (np.einsum("bij,bj->bi", Q[:, t], dx[:, t]) + np.einsum("bnm,bm->bn", M[:, t], V[:, t])
+               + np.einsum("bij,bi->bj", A[:, t], lam))
+    return out
+
+
 def cost_vjp(cmlp, mpc_w, goal, X, U, Hc, dX):
     """a11: d/d(cost_params, mpc_weights) of  H . grad_U J(U; theta).
 

@@ -54,13 +54,13 @@ def critic_flat(pb):
     return P.pack_critic(P.critic_oracle_to_tree(pb["critic"]))
 
 
-def near_kink(layers, q, thresh=2e-5):
-    """(rows,) bool: some hidden pre-activation is within `thresh` (relative to the layer's scale)
+def near_kink(layers, q, thresh=3e-6):
+    """(rows,) bool: some hidden pre-activation is within `thresh` (relative to that sample's layer scale)
     of the relu kink, where the derivative is discontinuous (hard part iii)."""
     _, zs = orc.mlp_forward(layers, q)
     bad = np.zeros(q.shape[0], bool)
     for z in zs:
-        bad |= (np.abs(z) < thresh * np.abs(z).max()).any(axis=1)
+        bad |= (np.abs(z) < thresh * np.abs(z).max(axis=1, keepdims=True)).any(axis=1)
     return bad
 
 
