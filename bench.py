@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- trajectories/sec of the GAN-MPC inner-loop step on MI355X.
+
+One "step"  on a batch of B synthetic trajectories per GPU:
+  1. rollout X from (x0, U) through the dynamics MLP + per-step costs          (gmpc_rollout_cost)
+  2. backward: linearise + quadratise + Riccati gains + adjoint gradient       (gmpc_lqr_backward_after_rollout)
+  3. critic step on 2B sequences (B "true" + the B rolled-out ones): BCE loss, BPTT,
+     [all-reduce of loss+grads over ranks], clip-by-global-norm(100) + Adam     (gmpc_critic_loss_grad, gmpc_adam_clip_step)
+All inputs are resident in HBM before the timed region.  fp32 throughout (the reference's dtype).
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one rank per GPU with torch.distributed.run (RCCL); per-GPU work is
+fixed (weak scaling), the only exchange is one all-reduce of the packed critic [loss | grads] buffer.
+Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# headline workload: BASELINE.json configs[2] shapes (HalfCheetah-sized, H=50, batch 1024, critic
+# LSTM(64) + 3x256 head); the metric names the critic step, so the critic config is the one timed.
+WORKLOAD = dict(name="C3 synthetic HalfCheetah-shape n=17 m=6 H=50 B=1024/GPU, dynamics MLP 4x200, "
+                     "cost MLP 3x128->10, critic LSTM(64)+3x256 head",
+                n=17, m=6, T=50, B=1024, dyn_hidden=(200, 200, 200), cost_hidden=(128, 128),
+                cost_fout=10, F=64, head_hidden=(256, 256, 256))
+
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+PEAK_HBM_GBS = 8000.0
+
+
+def linearize_flops_per_sample(n, m, dyn_dims):
+    """Algorithmic flops of one dynamics Jacobian (reverse chain, n rows): 2*n*(sum of hidden-hidden
+    products + first-layer product); SURVEY.md 8d 'Jacobian chain'."""
+    hh = sum(a * b for a, b in zip(dyn_dims[1:-2], dyn_dims[2:-1]))
+    return 2.0 * n * (hh + dyn_dims[1] * (n + m))
+
+
+def step_bytes_per_traj(n, m, T):
+    """SURVEY.md 8d algorithmic HBM bytes per trajectory-step of the fused rollout+backward."""
+    rd = n + T * m + (T + 1) * n
+    wr = (T + 1) * n + (T + 1) + T * (m * n + m) + T * m + (T + 1) * n
+    return 4.0 * (rd + wr)
+
+
+def cpu_baseline(args, w):
+    """The oracle (NumPy restatement, 'port') timed on this box's host cores on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import gan_mpc_oracle as orc
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:  # pragma: no cover
+        threadpool_limits = None
+    cores = os.cpu_count() or 1
+    Bs = args.cpu_sample
+    pb = orc.make_problem(w["n"], w["m"], w["T"], Bs, seed=0, dyn_hidden=w["dyn_hidden"],
+                          cost_hidden=w["cost_hidden"], cost_fout=w["cost_fout"],
+                          lstm_features=w["F"], head_hidden=w["head_hidden"])
+    label = np.concatenate([np.ones(Bs), -np.ones(Bs)]).astype(np.float32)
+
+    def one_step(state):
+        X = orc.rollout(pb["dyn"], pb["U"], pb["x0"])
+        orc.evaluate(pb["cmlp"], pb["mpc_w"], pb["goal"], X, pb["U"])
+        lqr = orc.get_lqr_params(pb["dyn"], pb["cmlp"], pb["mpc_w"], pb["goal"], X, pb["U"])
+        with np.errstate(all="ignore"):
+            orc.tvlqr(*lqr)
+        orc.adjoint(lqr[5], lqr[6], lqr[1], lqr[3])
+        xseq = np.concatenate([pb["true_seq"], X], 0)
+        _, g = orc.critic_loss_and_grad(pb["critic"], xseq, label)
+        flat = np.concatenate([g["Wx"].ravel(), g["Wh"].ravel(), g["b"].ravel()]
+                              + [t.ravel() for Wb in g["head"] for t in Wb])
+        p, mm, vv, k = state
+        p, mm, vv = orc.adam_clip_step(p, flat, mm, vv, k + 1, 1e-5)
+        return (p, mm, vv, k + 1)
+
+    import numpy as np  # noqa: F811
+    cnt = sum(v.size for v in (pb["critic"]["Wx"], pb["critic"]["Wh"], pb["critic"]["b"]))
+    cnt += sum(W.size + b.size for W, b in pb["critic"]["head"])
+    state = (np.zeros(cnt, np.float32), np.zeros(cnt, np.float32), np.zeros(cnt, np.float32), 0)
+    ctxm = threadpool_limits(limits=cores) if threadpool_limits else None
+    try:
+        state = one_step(state)  # warm-up
+        t0 = time.perf_counter()
+        reps = 0
+        while reps < 2 or time.perf_counter() - t0 < args.cpu_seconds:
+            state = one_step(state)
+            reps += 1
+        dt = time.perf_counter() - t0
+    finally:
+        if ctxm is not None:
+            ctxm.__exit__(None, None, None)
+    return {"value": Bs * reps / dt, "unit": "trajectories/sec", "cores": cores, "kind": "port",
+            "sample": f"{reps} steps of the NumPy oracle on {Bs} trajectories (same shapes, same step; "
+                      f"BLAS threads <= {cores})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=WORKLOAD["B"], help="trajectories per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=32)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks "
+                         f"(WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: gan_mpc_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gan_mpc_oracle as orc  # synthetic-problem generator only (inputs), never in the timed path
+    from gan_mpc_amd import params as P
+    from gan_mpc_amd.engine import Engine
+
+    w = dict(WORKLOAD)
+    B = args.batch
+    n, m, T, F = w["n"], w["m"], w["T"], w["F"]
+    pb = orc.make_problem(n, m, T, B, seed=1000 + rank, dyn_hidden=w["dyn_hidden"],
+                          cost_hidden=w["cost_hidden"], cost_fout=w["cost_fout"], lstm_features=F,
+                          head_hidden=w["head_hidden"])
+    wts = orc.make_problem(n, m, T, 1, seed=0, dyn_hidden=w["dyn_hidden"], cost_hidden=w["cost_hidden"],
+                           cost_fout=w["cost_fout"], lstm_features=F, head_hidden=w["head_hidden"])
+    dyn_dims = [n + m, *w["dyn_hidden"], n]
+    cost_dims = [n, *w["cost_hidden"], w["cost_fout"]]
+    head_dims = [F, *w["head_hidden"], 1]
+    eng = Engine(n, m, T, dyn_dims, cost_dims, max_batch=B, lstm_features=F, head_dims=head_dims,
+                 device=local_rank)
+    d = eng.to_dev
+    # identical (seed 0) parameters on every rank, rank-specific trajectories
+    eng.set_params(d(wts["mpc_w"]), d(P.pack_mlp(P.layers_to_tree(wts["dyn"]))),
+                   d(P.pack_mlp(P.layers_to_tree(wts["cmlp"]))))
+    critic = d(P.pack_critic(P.critic_oracle_to_tree(wts["critic"])))
+    adam_m, adam_v = torch.zeros_like(critic), torch.zeros_like(critic)
+    x0, U, goal = d(pb["x0"]), d(pb["U"]), d(pb["goal"])
+    xseq = eng.new(2 * B, T + 1, n)
+    xseq[:B].copy_(d(pb["true_seq"]))
+    label = d(np.concatenate([np.ones(B), -np.ones(B)]).astype(np.float32))
+    X = xseq[B:]                       # the rollout writes straight into the critic batch
+    costs = eng.new(B, T + 1)
+    bw = dict(K=eng.new(B, T, m, n), k=eng.new(B, T, m), grad=eng.new(B, T, m),
+              adjoints=eng.new(B, T + 1, n), AB=None)
+    packed = eng.new(1 + eng.critic_count)      # [loss_sum | grad_sum]: one all-reduce
+    loss_view, grad_view = packed[:1], packed[1:]
+    import ctypes as C
+    from gan_mpc_amd import _lib
+
+    def step(k):
+        eng.rollout_cost(x0, U, goal, X=X, costs=costs)
+        eng.lqr_backward(X, U, goal, after_rollout=True, out=bw)
+        _lib.check(eng.lib.gmpc_critic_loss_grad(
+            eng.ctx, 2 * B, C.c_void_p(xseq.data_ptr()), C.c_void_p(label.data_ptr()),
+            C.c_void_p(critic.data_ptr()), C.c_void_p(loss_view.data_ptr()),
+            C.c_void_p(grad_view.data_ptr()), eng._stream()))
+        if world > 1:
+            dist.all_reduce(packed)
+        eng.adam_clip_step(critic, grad_view, adam_m, adam_v, k + 1, lr=1e-5,
+                           grad_scale=1.0 / (2 * B * world))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
+    roof = None
+    prof = {}
+    if rank == 0:
+        eng.profile_enable(True)
+        nprof = min(args.steps, 10)
+        for k in range(nprof):
+            step(args.warmup + args.steps + k)
+        torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        dom = max(prof, key=lambda kk: prof[kk][0])
+        ms, cnt = prof["linearize"]
+        flops = linearize_flops_per_sample(n, m, dyn_dims) * B * T
+        ach = flops / (ms / cnt * 1e-3) / 1e12
+        roof = {"kernel": "k_linearize", "bound": "mfma", "achieved": round(ach, 3),
+                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+                "traffic": None,
+                "avg_launch_ms": round(ms / cnt, 4),
+                "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
+                "dominant_by_time": dom,
+                "hbm_view": {"algorithmic_bytes_per_step": step_bytes_per_traj(n, m, T) * B,
+                             "achieved_GBs_whole_step": round(
+                                 step_bytes_per_traj(n, m, T) * B / (ms_per_step * 1e-3) / 1e9, 2),
+                             "peak_GBs": PEAK_HBM_GBS},
+                "kernel_ms_per_step": {kk: round(v[0] / nprof, 4) for kk, v in prof.items() if v[1]}}
+        tr = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tr):
+            try:
+                roof["traffic"] = json.load(open(tr)).get("k_linearize_hbm_bytes_per_launch")
+            except Exception:
+                pass
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, w)
+
+    if rank == 0:
+        out = {
+            "metric": "trajectories/sec (rollout+backward+critic step) at batch=1024, H=50",
+            "value": round(value, 1), "unit": "trajectories/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": w["name"], "batch_per_gpu": B, "global_batch": B * world,
+                       "horizon": T, "state_dim": n, "act_dim": m,
+                       "parallelism": f"trajectory-sharded x{world}, 1 all-reduce of critic grads/step"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "gmpc_device.h"
@@ -38,6 +39,9 @@ void gmpc_launch_bvec(int, int, int, int, const float*, const float*, float*, hi
 void gmpc_launch_costvjp(int, int, int, int, const MlpDesc&, const float*, float, const float*,
                          const float*, const float*, const float*, const float*, float*, float*,
                          float*, int, hipStream_t);
+
+enum { PROF_ROLLOUT = 0, PROF_LINEARIZE, PROF_TERMINAL, PROF_RICCATI, PROF_LINESEARCH, PROF_LSTM_FWD,
+       PROF_HEAD, PROF_LSTM_BWD, PROF_WGRAD, PROF_ADAM };
 
 // error handling -------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -138,6 +142,22 @@ struct gmpc_ctx {
   // shared scratch
   float *wpart, *scratch;
   long wpart_floats;
+  // optional per-kernel timing with HIP events on the launch stream (gmpc_profile_*)
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[GMPC_PROF_SLOTS];
+};
+
+// RAII bracket: records a start/stop event pair around one kernel launch when profiling is on
+struct ProfScope {
+  gmpc_ctx* c; int slot; hipStream_t s; hipEvent_t e1 = nullptr;
+  ProfScope(gmpc_ctx* c_, int slot_, hipStream_t s_) : c(c_), slot(slot_), s(s_) {
+    if (!c->prof) return;
+    hipEvent_t e0;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e1 = nullptr; return; }
+    (void)hipEventRecord(e0, s);
+    c->prof_ev[slot].push_back({e0, e1});
+  }
+  ~ProfScope() { if (e1) (void)hipEventRecord(e1, s); }
 };
 
 template <typename Tp>
@@ -308,7 +328,10 @@ extern "C" int gmpc_rollout_cost(gmpc_ctx* c, int B, const float* x0, const floa
   hipStream_t s = static_cast<hipStream_t>(stream);
   TrajArgs a = base_traj(c, B, goal);
   a.x0 = x0; a.U = U; a.X = X; a.costs = costs; a.obj = c->obj; a.masks = c->masks;
-  gmpc_launch_rollout(a, s);
+  {
+    ProfScope ps(c, PROF_ROLLOUT, s);
+    gmpc_launch_rollout(a, s);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -318,10 +341,16 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
                          const int* active, float* K, float* k, float* grad, float* adj, float* AB,
                          int* cont, const gmpc_ilqr_opts* opts, hipStream_t s) {
   const gmpc_shape& sh = c->sh;
-  if (gmpc_launch_linearize(B, sh.T, sh.n, sh.m, c->dyn, c->masks, active, AB, s) != 0)
-    return fail(GMPC_EINVAL, "linearize: unsupported row count for n=%d", sh.n);
-  if (gmpc_launch_terminal(B, sh.T, sh.n, c->cost, c->mpc_w, X, active, c->QT, c->qT, s) != 0)
-    return fail(GMPC_EINVAL, "terminal: unsupported fout");
+  {
+    ProfScope ps(c, PROF_LINEARIZE, s);
+    if (gmpc_launch_linearize(B, sh.T, sh.n, sh.m, c->dyn, c->masks, active, AB, s) != 0)
+      return fail(GMPC_EINVAL, "linearize: unsupported row count for n=%d", sh.n);
+  }
+  {
+    ProfScope ps(c, PROF_TERMINAL, s);
+    if (gmpc_launch_terminal(B, sh.T, sh.n, c->cost, c->mpc_w, X, active, c->QT, c->qT, s) != 0)
+      return fail(GMPC_EINVAL, "terminal: unsupported fout");
+  }
   RiccatiArgs r;
   memset(&r, 0, sizeof(r));
   r.B = B; r.n = sh.n; r.m = sh.m; r.T = sh.T; r.mode = 0;
@@ -331,7 +360,10 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     r.cont = cont; r.iters = c->iters; r.obj = c->obj; r.alpha = c->alpha;
     r.obj_step = c->obj_step; r.U_step = c->U_step; r.opts = *opts;
   }
-  gmpc_launch_riccati(r, s);
+  {
+    ProfScope ps(c, PROF_RICCATI, s);
+    gmpc_launch_riccati(r, s);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -403,7 +435,10 @@ extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float*
     bool any = false;
     for (int b = 0; b < B; ++b) any |= hcont[b] != 0;
     if (!any) break;
-    gmpc_launch_linesearch(ls, s);
+    {
+      ProfScope ps(c, PROF_LINESEARCH, s);
+      gmpc_launch_linesearch(ls, s);
+    }
     TRY(backward_pass(c, B, c->Xs, c->Us, c->goals, c->cont, c->Ks, c->ks, c->grads, c->adjs, c->AB,
                       c->cont, opts, s));
   }
@@ -443,12 +478,21 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
   TRY(bind_critic(c, critic, cd, s));
   const gmpc_shape& sh = c->sh;
   const int n = sh.n, F = sh.lstm_features, T1 = sh.T + 1;
-  gmpc_launch_lstm_fwd(Bc, cd, xseq, c->gates, c->cs, c->hp, c->hT, s);
-  gmpc_launch_head(Bc, cd, loss_kind, c->hT, label, c->cscore, c->closs, c->hacts, c->hdels, c->dhT,
-                   c->hstride, s);
-  if (dxseq || want_wgrad)
+  {
+    ProfScope ps(c, PROF_LSTM_FWD, s);
+    gmpc_launch_lstm_fwd(Bc, cd, xseq, c->gates, c->cs, c->hp, c->hT, s);
+  }
+  {
+    ProfScope ps(c, PROF_HEAD, s);
+    gmpc_launch_head(Bc, cd, loss_kind, c->hT, label, c->cscore, c->closs, c->hacts, c->hdels, c->dhT,
+                     c->hstride, s);
+  }
+  if (dxseq || want_wgrad) {
+    ProfScope ps(c, PROF_LSTM_BWD, s);
     gmpc_launch_lstm_bwd(Bc, cd, c->gates, c->cs, c->dhT, want_wgrad ? c->dz : nullptr, dxseq, s);
+  }
   if (want_wgrad) {
+    ProfScope ps(c, PROF_WGRAD, s);
     const int rows = Bc * T1, G4 = 4 * F;
     float* gWx = grad_sum;
     float* gWh = gWx + (long)n * G4;
@@ -549,9 +593,39 @@ extern "C" int gmpc_adam_clip_step(gmpc_ctx* c, long count, float* params, const
   if (count < 1 || step < 1) return fail(GMPC_EINVAL, "count and step must be positive");
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  gmpc_launch_adam(count, params, grad, m, v, grad_scale, step, lr, max_norm, b1, b2, eps, c->scratch,
-                   s);
+  {
+    ProfScope ps(c, PROF_ADAM, s);
+    gmpc_launch_adam(count, params, grad, m, v, grad_scale, step, lr, max_norm, b1, b2, eps,
+                     c->scratch, s);
+  }
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmpc_profile_enable(gmpc_ctx* c, int on) {
+  if (!c) return fail(GMPC_EINVAL, "ctx is null");
+  c->prof = on != 0;
+  return 0;
+}
+
+extern "C" int gmpc_profile_read(gmpc_ctx* c, int slot, double* total_ms, int* count) {
+  if (!c || slot < 0 || slot >= GMPC_PROF_SLOTS || !total_ms || !count)
+    return fail(GMPC_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  double tot = 0.0;
+  int n = 0;
+  for (auto& pr : c->prof_ev[slot]) {
+    HIP_TRY(hipEventSynchronize(pr.second));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+    tot += ms;
+    ++n;
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  c->prof_ev[slot].clear();
+  *total_ms = tot;
+  *count = n;
   return 0;
 }
 

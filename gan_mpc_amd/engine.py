@@ -179,6 +179,21 @@ class Engine:
             self.ctx, params.numel(), _ptr(params), _ptr(grad), _ptr(m), _ptr(v), float(grad_scale),
             int(step), float(lr), float(max_norm), float(b1), float(b2), float(eps), self._stream()))
 
+    PROF_SLOTS = ("rollout", "linearize", "terminal", "riccati", "linesearch", "lstm_fwd", "head",
+                  "lstm_bwd", "wgrad", "adam")
+
+    def profile_enable(self, on=True):
+        _lib.check(self.lib.gmpc_profile_enable(self.ctx, int(bool(on))))
+
+    def profile_read(self):
+        """{kernel: (total_ms, launches)} since the last read (HIP events on the launch stream)."""
+        out = {}
+        for i, name in enumerate(self.PROF_SLOTS):
+            ms, cnt = C.c_double(), C.c_int()
+            _lib.check(self.lib.gmpc_profile_read(self.ctx, i, C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
+
     def debug_buffer(self, which, shape):
         """Copy of one of the ctx's internal solution buffers (see gmpc_debug_buffer)."""
         p = self.lib.gmpc_debug_buffer(self.ctx, which)

@@ -32,6 +32,7 @@ extern "C" {
 #endif
 
 #define GMPC_MAX_LAYERS 8
+#define GMPC_PROF_SLOTS 10
 
 enum {
   GMPC_OK = 0,
@@ -146,6 +147,14 @@ int gmpc_critic_score_vjp(gmpc_ctx* ctx, int Bc, const float* xseq, const float*
 int gmpc_adam_clip_step(gmpc_ctx* ctx, long count, float* params, const float* grad, float* m,
                         float* v, float grad_scale, int step, double lr, double max_norm, double b1,
                         double b2, double eps, void* stream);
+
+/* Optional per-kernel timing with HIP events recorded on the launch stream around each kernel
+ * (bench.py's roofline leg).  Slots: 0 rollout, 1 linearize, 2 terminal, 3 riccati, 4 linesearch,
+ * 5 lstm_fwd, 6 head, 7 lstm_bwd, 8 wgrad (all weight-gradient GEMMs of one critic call), 9 adam.
+ * gmpc_profile_read waits for the recorded events, returns the summed milliseconds and the number
+ * of launches of that slot since the last read, and resets the slot. */
+int gmpc_profile_enable(gmpc_ctx* ctx, int on);
+int gmpc_profile_read(gmpc_ctx* ctx, int slot, double* total_ms, int* count);
 
 /* Device pointers into the ctx's solution of the last gmpc_ilqr_solve / gmpc_bilevel_grad (valid
  * until the next such call): 0 X, 1 U, 2 H = A^-1 B, 3 dX, 4 Bvec, 5 AB, 6 K, 7 k.
