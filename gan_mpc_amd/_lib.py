@@ -56,6 +56,8 @@ SIGNATURES = {
     "gmpc_ilqr_solve": (C.c_int, [_P, C.c_int, _P, _P, _P, C.POINTER(IlqrOpts), _P, _P, _P, _P, _P,
                                   _P, _P]),
     "gmpc_bilevel_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P]),
+    "gmpc_upper_loss": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "gmpc_polyak": (C.c_int, [_P, C.c_long, _P, _P, C.c_double, _P, _P]),
     "gmpc_critic_loss_grad": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "gmpc_critic_score_vjp": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),
     "gmpc_adam_clip_step": (C.c_int, [_P, C.c_long, _P, _P, _P, _P, C.c_float, C.c_int, C.c_double,

@@ -34,6 +34,7 @@ void gmpc_launch_wgrad(int, int, int, const float*, int, const float*, int, floa
 void gmpc_launch_sum(int, const float*, float*, int, hipStream_t);
 void gmpc_launch_adam(long, float*, const float*, float*, float*, float, int, double, double, double,
                       double, double, float*, hipStream_t);
+void gmpc_launch_polyak(long, const float*, const float*, double, float*, hipStream_t);
 void gmpc_launch_l2loss(int, int, int, const float*, const float*, float*, float*, hipStream_t);
 void gmpc_launch_bvec(int, int, int, int, const float*, const float*, float*, hipStream_t);
 void gmpc_launch_costvjp(int, int, int, int, const MlpDesc&, const float*, float, const float*,
@@ -540,6 +541,43 @@ extern "C" int gmpc_critic_score_vjp(gmpc_ctx* c, int Bc, const float* xseq, con
   return 0;
 }
 
+// upper-level loss only, at the solution held by the ctx (norm/cost_trainer.py:13-21 test loss)
+static int upper_loss(gmpc_ctx* c, int B, int loss_kind, const float* desired, const float* critic,
+                      float* loss, bool want_lx, hipStream_t s) {
+  const gmpc_shape& sh = c->sh;
+  if (loss_kind == 0) {
+    if (!desired) return fail(GMPC_EINVAL, "desired is null");
+    gmpc_launch_l2loss(B, sh.T, sh.n, c->Xs, desired, loss, c->lx, s);
+  } else if (loss_kind == 1) {
+    if (!critic) return fail(GMPC_EINVAL, "critic is null");
+    TRY(critic_forward_backward(c, B, c->Xs, nullptr, critic, 1, want_lx ? c->lx : nullptr, false,
+                                nullptr, s));
+    HIP_TRY(hipMemcpyAsync(loss, c->closs, B * sizeof(float), hipMemcpyDeviceToDevice, s));
+  } else {
+    return fail(GMPC_EINVAL, "loss_kind must be 0 (L2) or 1 (JS)");
+  }
+  return 0;
+}
+
+extern "C" int gmpc_upper_loss(gmpc_ctx* c, int B, int loss_kind, const float* desired,
+                               const float* critic, float* loss, void* stream) {
+  TRY(check_call(c, B));
+  if (c->solB != B) return fail(GMPC_EINVAL, "gmpc_ilqr_solve with B=%d must precede this call", B);
+  if (!loss) return fail(GMPC_EINVAL, "null argument");
+  TRY(upper_loss(c, B, loss_kind, desired, critic, loss, false, static_cast<hipStream_t>(stream)));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+extern "C" int gmpc_polyak(gmpc_ctx* c, long count, const float* prev, const float* cur, double factor,
+                           float* out, void* stream) {
+  if (!c || !prev || !cur || !out || count < 1) return fail(GMPC_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  gmpc_launch_polyak(count, prev, cur, factor, out, static_cast<hipStream_t>(stream));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // bilevel ----------------------------------------------------------------------------------------
 extern "C" int gmpc_bilevel_grad(gmpc_ctx* c, int B, int loss_kind, const float* desired,
                                  const float* critic, float sign, float* loss, float* grad_sum,
@@ -550,16 +588,7 @@ extern "C" int gmpc_bilevel_grad(gmpc_ctx* c, int B, int loss_kind, const float*
   hipStream_t s = static_cast<hipStream_t>(stream);
   const gmpc_shape& sh = c->sh;
   const int n = sh.n, m = sh.m, T = sh.T;
-  if (loss_kind == 0) {
-    if (!desired) return fail(GMPC_EINVAL, "desired is null");
-    gmpc_launch_l2loss(B, T, n, c->Xs, desired, loss, c->lx, s);
-  } else if (loss_kind == 1) {
-    if (!critic) return fail(GMPC_EINVAL, "critic is null");
-    TRY(critic_forward_backward(c, B, c->Xs, nullptr, critic, 1, c->lx, false, nullptr, s));
-    HIP_TRY(hipMemcpyAsync(loss, c->closs, B * sizeof(float), hipMemcpyDeviceToDevice, s));
-  } else {
-    return fail(GMPC_EINVAL, "loss_kind must be 0 (L2) or 1 (JS)");
-  }
+  TRY(upper_loss(c, B, loss_kind, desired, critic, loss, true, s));
   // a8: Bvec; a9+solve: structured Hessian solve; a11: cost_vjp
   gmpc_launch_bvec(B, T, n, m, c->AB, c->lx, c->Bvec, s);
   RiccatiArgs r;

@@ -389,6 +389,13 @@ __global__ void k_adam(long count, float* p, const float* g, float* m, float* v,
   p[e] = p[e] + (-lr * mh / (sqrtf(vh) + eps));
 }
 
+// Polyak blend (norm/cost_trainer.py:88-92): out = f * prev + (1 - f) * cur
+__global__ void k_polyak(long count, const float* prev, const float* cur, float f, float omf,
+                         float* out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < count) out[e] = f * prev[e] + omf * cur[e];
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
@@ -464,4 +471,10 @@ void gmpc_launch_adam(long count, float* p, const float* g, float* m, float* v, 
   hipLaunchKernelGGL(k_adam, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, count, p, g, m, v,
                      scale, scratch, (float)max_norm, (float)lr, (float)b1, (float)b2,
                      (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, bc1, bc2);
+}
+
+void gmpc_launch_polyak(long count, const float* prev, const float* cur, double f, float* out,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(k_polyak, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, count, prev, cur,
+                     (float)f, (float)(1.0 - f), out);
 }

@@ -1,0 +1,30 @@
+"""Dynamics model wrapper (reference dynamics/dynamics_model.py:11-48)."""
+
+import numpy as np
+
+from gan_mpc_amd import base
+
+
+class DynamicsModel(base.BaseDynamicsModel):
+    def __init__(self, config, model):
+        super().__init__(config)
+        self.model = model
+
+    def init(self, *args):
+        model_args = self.model.get_init_params(*args)
+        return self.model.init(*model_args)
+
+    def get_zero_carry(self, history_x):
+        xsize = np.shape(history_x)[1]
+        return self.model.get_carry(np.zeros(xsize, np.float32))
+
+    def get_history_carry(self, history_x, history_u, params):
+        # MLP dynamics: the carry is empty whatever the history (dynamics/nn.py:15-17)
+        return self.get_zero_carry(history_x)
+
+    def predict(self, xc, u, t, params, policy=None):
+        """next state of one (xc, u): the rollout kernel on a one-step trajectory."""
+        del t
+        if policy is None:
+            raise ValueError("predict needs the policy that owns the HIP engine (policy=...)")
+        return policy.single_predict(xc, u, params)

@@ -157,6 +157,18 @@ class Engine:
                                               float(sign), _ptr(loss), _ptr(grad_sum), self._stream()))
         return loss, grad_sum
 
+    def upper_loss(self, B, loss_kind, desired=None, critic=None):
+        loss = self.new(B)
+        _lib.check(self.lib.gmpc_upper_loss(self.ctx, B, int(loss_kind), _ptr(desired), _ptr(critic),
+                                            _ptr(loss), self._stream()))
+        return loss
+
+    def polyak(self, prev, cur, factor, out=None):
+        out = cur if out is None else out
+        _lib.check(self.lib.gmpc_polyak(self.ctx, prev.numel(), _ptr(prev), _ptr(cur), float(factor),
+                                        _ptr(out), self._stream()))
+        return out
+
     def critic_loss_grad(self, xseq, label, critic):
         Bc = xseq.shape[0]
         loss_sum = self.new(1)

@@ -1,0 +1,71 @@
+"""Jensen-Shannon policy (reference gan/js_policy.py:11-74): BCE critic loss with +-1 labels,
+generator loss -log s + log(1 - s) on the iLQR state sequence."""
+
+import numpy as np
+import torch
+
+from gan_mpc_amd import parallel
+from gan_mpc_amd.engine import TRAJAX_iLQR_KWARGS
+from gan_mpc_amd.policy import base
+
+
+class JS_MPC(base.BaseMPC):
+    LOSS_KIND = 1
+
+    def __init__(self, config, cost_model, dynamics_model, expert_model, critic_model,
+                 loss_vmap=(0,), trajax_ilqr_kwargs=TRAJAX_iLQR_KWARGS, device=None,
+                 bilevel_sign=1.0):
+        self.critic_model = critic_model
+        super().__init__(config, cost_model, dynamics_model, expert_model, loss_vmap,
+                         trajax_ilqr_kwargs, device=device, bilevel_sign=bilevel_sign)
+        self.critic_model = critic_model
+
+    def init(self, mpc_weights, cost_args, dynamics_args, expert_args, critic_args):
+        params = super().init(mpc_weights, cost_args, dynamics_args, expert_args)
+        params["critic_params"] = self.critic_model.init(*critic_args)
+        return params
+
+    def critic_scores(self, xseq, params):
+        dparams = self.to_device_params(params)
+        single = np.ndim(xseq) == 2
+        xs = xseq[None] if single else xseq
+        eng = self.engine_for(max(1, (xs.shape[0] + 1) // 2), dparams)
+        xs = xs if torch.is_tensor(xs) else eng.to_dev(xs)
+        score, _ = eng.critic_score_vjp(xs.contiguous(), dparams.view("critic_params"), want_dx=False)
+        return score[:1] if single else score
+
+    def critic_loss(self, xseq, label, params):
+        """-log p, p = sigmoid(score) if label > 0 else 1 - sigmoid(score)  (js_policy.py:41-46)."""
+        dparams = self.to_device_params(params)
+        xs = xseq[None] if np.ndim(xseq) == 2 else xseq
+        lab = np.atleast_1d(np.asarray(label, np.float32))
+        loss, _ = self._critic_sums(xs, lab, dparams)
+        return loss / len(lab)
+
+    def _critic_sums(self, batch_xseq, batch_label, dparams):
+        Bc = batch_xseq.shape[0]
+        eng = self.engine_for((Bc + 1) // 2, dparams)
+        xs = batch_xseq if torch.is_tensor(batch_xseq) else eng.to_dev(batch_xseq)
+        lab = batch_label if torch.is_tensor(batch_label) else eng.to_dev(batch_label)
+        ls, gs = eng.critic_loss_grad(xs.contiguous(), lab.contiguous(), dparams.view("critic_params"))
+        return ls[0], gs
+
+    def critic_loss_and_grad(self, batch_xseq, batch_label, params):
+        """reference gan/js_policy.py:48-58: (mean loss, grads wrt critic_params as a flat device
+        vector; every other leaf's gradient is zero).  The batch is this rank's shard; the mean is
+        global (one all-reduce of [loss_sum | grad_sum])."""
+        dparams = self.to_device_params(params)
+        ls, gs = self._critic_sums(batch_xseq, batch_label, dparams)
+        packed = torch.cat([ls.reshape(1), gs])
+        parallel.allreduce_mean_from_sums(packed, batch_xseq.shape[0])
+        return packed[0], packed[1:]
+
+    def generator_loss_and_grad(self, batch_xseq, params, batch_loss_args):
+        return self.loss_and_grad(batch_xseq, params, batch_loss_args)
+
+    def generator_loss(self, xcseq, useq, params, actual_xseq):
+        del useq, actual_xseq
+        return -self.critic_scores(xcseq, params)  # -log s + log(1-s) == -score (js_policy.py:66-68)
+
+    def loss(self, xcseq, useq, params, desired_xseq):
+        return self.generator_loss(xcseq, useq, params, desired_xseq)

@@ -1,0 +1,27 @@
+"""Parameter initialisation with flax's Dense defaults: LeCun-normal kernels (variance 1/fan_in),
+zero biases; OptimizedLSTMCell input kernels LeCun-normal (flax uses orthogonal recurrent kernels --
+here LeCun-normal too; initial values only, no arithmetic on the path depends on it).  The stream is
+numpy's, not JAX's threefry: `seed` reproduces within this package, not against flax."""
+
+import numpy as np
+
+
+def dense_tree(rng, dims):
+    p = {}
+    for k, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        p[f"Dense_{k}"] = {
+            "kernel": (rng.standard_normal((a, b)) / np.sqrt(a)).astype(np.float32),
+            "bias": np.zeros(b, np.float32),
+        }
+    return {"params": p}
+
+
+def lstm_critic_tree(rng, n, F, head_dims, scope="ScanOptimizedLSTMCell_0"):
+    cell = {}
+    for g in "ifgo":
+        cell["i" + g] = {"kernel": (rng.standard_normal((n, F)) / np.sqrt(n)).astype(np.float32)}
+        cell["h" + g] = {"kernel": (rng.standard_normal((F, F)) / np.sqrt(F)).astype(np.float32),
+                         "bias": np.zeros(F, np.float32)}
+    p = {scope: cell}
+    p.update(dense_tree(rng, head_dims)["params"])
+    return {"params": p}

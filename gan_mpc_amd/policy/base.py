@@ -1,0 +1,66 @@
+"""Training-time policy (reference policy/base.py:12-128): zero dynamics carry, loss_and_grad =
+batched bilevel optimisation + batch mean (+ the multi-GPU all-reduce at exactly that mean)."""
+
+import numpy as np
+import torch
+
+from gan_mpc_amd import parallel
+from gan_mpc_amd.engine import TRAJAX_iLQR_KWARGS
+from gan_mpc_amd.policy import eval as eval_policy
+from gan_mpc_amd.policy import optimizers as opt
+
+
+class BaseMPC(eval_policy.EvalMPC):
+    LOSS_KIND = None  # 0: L2, 1: JS generator
+
+    def __init__(self, config, cost_model, dynamics_model, expert_model, loss_vmap=(0,),
+                 trajax_ilqr_kwargs=TRAJAX_iLQR_KWARGS, device=None, bilevel_sign=1.0):
+        super().__init__(config=config, cost_model=cost_model, dynamics_model=dynamics_model,
+                         expert_model=expert_model, trajax_ilqr_kwargs=trajax_ilqr_kwargs,
+                         device=device)
+        self.loss_vmap = loss_vmap
+        # +1 reproduces the reference as written; -1 is the implicit-function gradient
+        self.bilevel_sign = float(bilevel_sign)
+
+    def get_dynamics_carry(self, history_x, *args):
+        del args
+        return self.dynamics_model.get_zero_carry(np.asarray(history_x)[:-1])
+
+    def get_optimal_values(self, params, history_x, *args):
+        del args
+        return super().get_optimal_values(params, history_x)
+
+    def loss(self, xcseq, useq, params, *args):
+        raise NotImplementedError
+
+    def batch_loss(self, dparams, history_X, desired):
+        """mean over the (global) batch of loss(iLQR(x)) -- norm/cost_trainer.py:13-21."""
+        dparams, sol = self._solve(dparams, history_X)
+        B = sol["X"].shape[0]
+        eng = self._engine
+        crit = dparams.view("critic_params") if self.LOSS_KIND == 1 else None
+        loss = eng.upper_loss(B, self.LOSS_KIND, desired=eng.to_dev(desired) if desired is not None
+                              else None, critic=crit)
+        packed = loss.sum().reshape(1)
+        return parallel.allreduce_mean_from_sums(packed, B)[0]
+
+    def loss_and_grad(self, history_X, params, batch_loss_args):
+        """reference policy/base.py:87-128.  history_X (B, hist+1, n) is THIS rank's shard;
+        returns (avg_loss, grads) where grads is a flat device vector over [mpc_weights | cost_params]
+        (every other leaf's gradient is exactly zero in the reference), both averaged
+        over the global batch."""
+        if self.LOSS_KIND is None:
+            raise NotImplementedError
+        dparams = self.to_device_params(params)
+        hx = np.asarray(history_X, np.float32)
+        B = hx.shape[0]
+        goal, init_U = self.get_goal_states_init_actions(hx, dparams)
+        eng = self.engine_for(B, dparams)
+        d = eng.to_dev
+        desired = d(batch_loss_args[0]) if batch_loss_args and batch_loss_args[0] is not None else None
+        loss, _, grad_sum, _ = opt.bilevel_optimization(
+            self, dparams, d(hx[:, -1]), d(init_U), d(goal), self.LOSS_KIND, desired=desired,
+            sign=self.bilevel_sign)
+        packed = torch.cat([loss.sum().reshape(1), grad_sum])
+        parallel.allreduce_mean_from_sums(packed, B)
+        return packed[0], packed[1:]

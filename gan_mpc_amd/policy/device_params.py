@@ -1,0 +1,74 @@
+"""Parameters as ONE flat fp32 device vector  [mpc_weights(3) | cost | dynamics | critic]  with named
+views, so that the trainable ranges of the reference's two optimisers are contiguous:
+cost step = mpc_weights + cost_params (gan/runner.py:51-63 with yaml no_grads), critic step =
+critic_params."""
+
+import numpy as np
+import torch
+
+from gan_mpc_amd import params as P
+
+
+class DeviceParams:
+    KEYS = ("mpc_weights", "cost_params", "dynamics_params", "critic_params")
+
+    def __init__(self, flat, sizes, meta, expert_params=None):
+        self.flat = flat
+        self.sizes = sizes          # dict key -> count
+        self.meta = meta            # dims needed to rebuild the trees
+        self.expert_params = expert_params
+        self.offsets = {}
+        off = 0
+        for k in self.KEYS:
+            self.offsets[k] = off
+            off += sizes[k]
+
+    def view(self, key):
+        o = self.offsets[key]
+        return self.flat[o:o + self.sizes[key]]
+
+    def range_of(self, keys):
+        """(offset, count) of a set of keys; they must be adjacent in the flat layout."""
+        ks = [k for k in self.KEYS if k in keys and self.sizes[k] > 0]
+        lo = self.offsets[ks[0]]
+        hi = self.offsets[ks[-1]] + self.sizes[ks[-1]]
+        if hi - lo != sum(self.sizes[k] for k in ks):
+            raise ValueError(f"trainable keys {ks} are not contiguous")
+        return lo, hi - lo
+
+    def clone(self):
+        return DeviceParams(self.flat.clone(), self.sizes, self.meta, self.expert_params)
+
+    @staticmethod
+    def from_tree(params, device):
+        cost = P.pack_mlp(params["cost_params"])
+        dyn = P.pack_mlp(params["dynamics_params"])
+        crit = (P.pack_critic(params["critic_params"]) if params.get("critic_params") is not None
+                else np.zeros(0, np.float32))
+        mpc = np.asarray(params["mpc_weights"], np.float32).reshape(3)
+        meta = dict(cost_dims=P.mlp_dims(params["cost_params"]),
+                    dyn_dims=P.mlp_dims(params["dynamics_params"]),
+                    critic=(P.critic_dims(params["critic_params"])
+                            if params.get("critic_params") is not None else None))
+        flat = torch.from_numpy(np.concatenate([mpc, cost, dyn, crit])).to(device)
+        sizes = dict(mpc_weights=3, cost_params=cost.size, dynamics_params=dyn.size,
+                     critic_params=crit.size)
+        return DeviceParams(flat, sizes, meta, params.get("expert_params"))
+
+    def to_tree(self):
+        h = self.flat.detach().cpu().numpy()
+        o = self.offsets
+        out = {
+            "mpc_weights": h[o["mpc_weights"]:o["mpc_weights"] + 3].copy(),
+            "cost_params": P.unpack_mlp(h[o["cost_params"]:o["cost_params"] + self.sizes["cost_params"]],
+                                        self.meta["cost_dims"]),
+            "dynamics_params": P.unpack_mlp(
+                h[o["dynamics_params"]:o["dynamics_params"] + self.sizes["dynamics_params"]],
+                self.meta["dyn_dims"]),
+            "expert_params": self.expert_params,
+        }
+        if self.meta["critic"] is not None:
+            n, F, head = self.meta["critic"]
+            out["critic_params"] = P.unpack_critic(
+                h[o["critic_params"]:o["critic_params"] + self.sizes["critic_params"]], n, F, head)
+        return out

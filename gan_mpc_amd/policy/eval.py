@@ -1,0 +1,154 @@
+"""Evaluation policy (reference policy/eval.py:25-128): holds the models, builds the solver,
+get_optimal_values / get_optimal_action.  Accepts one sample (hist+1, n) like the reference or a
+batch (B, hist+1, n)."""
+
+import numpy as np
+import torch
+
+from gan_mpc_amd.engine import TRAJAX_iLQR_KWARGS, Engine
+from gan_mpc_amd.policy import optimizers as opt
+from gan_mpc_amd.policy.device_params import DeviceParams
+
+COST_ARGS_NAME = ("goal_state",)
+
+
+class EvalMPC:
+    def __init__(self, config, cost_model, dynamics_model, expert_model,
+                 trajax_ilqr_kwargs=TRAJAX_iLQR_KWARGS, device=None):
+        self.config = config
+        self.cost_model = cost_model
+        self.dynamics_model = dynamics_model
+        self.expert_model = expert_model
+        self.trajax_ilqr_kwargs = dict(trajax_ilqr_kwargs)
+        self.critic_model = getattr(self, "critic_model", None)
+        self._device = device
+        self._engine = None
+        self._engine_key = None
+        self._bound = None
+        self._single = None
+
+    # ---- parameters -------------------------------------------------------------------------
+    def init(self, mpc_weights, cost_args, dynamics_args, expert_args):
+        params = {}
+        params["mpc_weights"] = np.array(mpc_weights, dtype=np.float32)
+        params["cost_params"] = self.cost_model.init(*cost_args)
+        params["dynamics_params"] = self.dynamics_model.init(*dynamics_args)
+        params["expert_params"] = self.expert_model.init(*expert_args)
+        return params
+
+    def device(self):
+        if self._device is None:
+            self._device = torch.device("cuda", torch.cuda.current_device())
+        return self._device
+
+    def to_device_params(self, params):
+        return params if isinstance(params, DeviceParams) else DeviceParams.from_tree(params, self.device())
+
+    # ---- engine -----------------------------------------------------------------------------
+    def _shape_key(self, dparams):
+        return (tuple(dparams.meta["dyn_dims"]), tuple(dparams.meta["cost_dims"]),
+                None if dparams.meta["critic"] is None else
+                (dparams.meta["critic"][1], tuple(dparams.meta["critic"][2])))
+
+    def engine_for(self, batch, dparams=None):
+        dparams = dparams or self._bound
+        key = self._shape_key(dparams)
+        if self._engine is None or self._engine_key != key or batch > self._engine.max_batch:
+            if self._engine is not None:
+                self._engine.close()
+            dyn_dims, cost_dims = dparams.meta["dyn_dims"], dparams.meta["cost_dims"]
+            n = dyn_dims[-1]
+            m = dyn_dims[0] - n
+            cr = dparams.meta["critic"]
+            self._engine = Engine(n, m, self.config.mpc.horizon, dyn_dims, cost_dims,
+                                  max_batch=max(batch, 8), lstm_features=cr[1] if cr else 0,
+                                  head_dims=cr[2] if cr else None, device=self.device().index)
+            self._engine_key = key
+            self._bound_ptr = None
+        return self._engine
+
+    def bind(self, dparams, batch=1):
+        """Engine sized for `batch` with the ctx pointed at this parameter vector (rebuilds the
+        transposed weight copies)."""
+        self._bound = dparams
+        eng = self.engine_for(batch, dparams)
+        eng.set_params(dparams.view("mpc_weights"), dparams.view("dynamics_params"),
+                       dparams.view("cost_params"))
+        return eng
+
+    # ---- reference API ----------------------------------------------------------------------
+    def get_dynamics_carry(self, history_x, history_u, params):
+        return self.dynamics_model.get_history_carry(history_x[:-1], history_u, None)
+
+    def get_goal_states_init_actions(self, history_X, params):
+        expert_params = params.expert_params if isinstance(params, DeviceParams) else params.get(
+            "expert_params")
+        return self.expert_model.get_goal_states_init_actions(history_X, expert_params)
+
+    def _solve(self, params, history_X):
+        dparams = self.to_device_params(params)
+        hx = np.asarray(history_X, np.float32)
+        goal, init_U = self.get_goal_states_init_actions(hx, dparams)
+        eng = self.engine_for(hx.shape[0], dparams)
+        d = eng.to_dev
+        # xc = concat[x, carry]; the MLP dynamics' carry is empty (policy/eval.py:118-123)
+        sol = opt.ilqr_solve(self, dparams, d(hx[:, -1]), d(init_U), d(goal))
+        return dparams, sol
+
+    def get_optimal_values(self, params, history_x, history_u=None):
+        """-> (X, U, obj, gradient, adjoints, lqr, iteration), the 7-tuple of trajax ilqr.  `lqr`
+        is the device-resident [A_t | B_t] block of the final linearisation."""
+        single = np.ndim(history_x) == 2
+        hx = np.asarray(history_x, np.float32)[None] if single else history_x
+        _, sol = self._solve(params, hx)
+        B = sol["X"].shape[0]
+        eng = self._engine
+        lqr = eng.debug_buffer(5, (B, eng.T, eng.n, eng.n + eng.m))
+        out = (sol["X"], sol["U"], sol["obj"], sol["grad"], sol["adjoints"], lqr, sol["iterations"])
+        if single:
+            out = tuple(o[0] for o in out)
+        return out
+
+    def get_optimal_action(self, params, history_x, history_u=None):
+        _, useq, *_ = self.get_optimal_values(params, history_x, history_u)
+        return useq[0] if useq.dim() == 2 else useq[:, 0]
+
+    # ---- single-sample model evaluations (cost_model.get_cost / dynamics_model.predict) --------
+    def _single_engine(self, dparams):
+        key = self._shape_key(dparams)
+        if self._single is None or self._single[0] != key:
+            dyn_dims, cost_dims = dparams.meta["dyn_dims"], dparams.meta["cost_dims"]
+            n = dyn_dims[-1]
+            eng = Engine(n, dyn_dims[0] - n, 1, dyn_dims, cost_dims, max_batch=8,
+                         device=self.device().index)
+            self._single = (key, eng)
+        eng = self._single[1]
+        eng.set_params(dparams.view("mpc_weights"), dparams.view("dynamics_params"),
+                       dparams.view("cost_params"))
+        return eng
+
+    def single_predict(self, xc, u, params):
+        dparams = self.to_device_params(params)
+        eng = self._single_engine(dparams)
+        d = eng.to_dev
+        x = np.asarray(xc, np.float32).reshape(1, -1)
+        X, _ = eng.rollout_cost(d(x), d(np.asarray(u, np.float32).reshape(1, 1, -1)),
+                                d(np.zeros((1, 2, x.shape[1]), np.float32)))
+        return X[0, 1]
+
+    def single_cost(self, xc, u, t, params, weights, goal_X):
+        dparams = self.to_device_params(params)
+        if weights is not None:
+            dparams = dparams.clone()
+            dparams.view("mpc_weights").copy_(torch.as_tensor(np.asarray(weights, np.float32)))
+        eng = self._single_engine(dparams)
+        d = eng.to_dev
+        x = np.asarray(xc, np.float32).reshape(1, -1)
+        if t == self.config.mpc.horizon:
+            raise NotImplementedError(
+                "terminal cost of an arbitrary state: use get_optimal_values / rollout_cost, whose "
+                "last cost entry is the terminal cost of the rollout's final state")
+        g = np.zeros((1, 2, x.shape[1]), np.float32)
+        g[0, 0] = goal_X[min(t, len(goal_X) - 1)]
+        _, costs = eng.rollout_cost(d(x), d(np.asarray(u, np.float32).reshape(1, 1, -1)), d(g))
+        return costs[0, 0]

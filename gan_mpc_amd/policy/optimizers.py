@@ -1,0 +1,26 @@
+"""Trajectory optimiser entry points with the reference's names (reference policy/optimizers.py).
+
+The reference passes `cost` / `dynamics` callables to trajax; here the iLQR loop, the model
+evaluations and their derivatives are fused HIP kernels behind the C ABI, so the callables are
+replaced by the policy object that owns the engine and the bound parameters.  Everything is batched
+over the leading axis (the reference's jax.vmap axis)."""
+
+
+def ilqr_solve(policy, dparams, x0, U, goal, trajax_ilqr_kwargs=None):
+    """reference policy/optimizers.py:10-21 -> trajax ilqr.  Device tensors in, dict of device
+    tensors out: X, U, obj, grad, adjoints, iterations (the `lqr` tuple stays in the ctx)."""
+    eng = policy.bind(dparams, x0.shape[0])
+    return eng.ilqr_solve(x0, U, goal, trajax_ilqr_kwargs or policy.trajax_ilqr_kwargs)
+
+
+def bilevel_optimization(policy, dparams, x0, init_U, goal, loss_kind, desired=None,
+                         trajax_ilqr_kwargs=None, sign=1.0):
+    """reference policy/optimizers.py:34-75, batched, WITHOUT the batch mean: returns
+    (loss [B], low_level_grad [B,T,m], grad_sum [3 + cost_count] summed over the batch, itr [B]).
+    sign=+1 reproduces the reference as written."""
+    B = x0.shape[0]
+    eng = policy.bind(dparams, B)
+    sol = eng.ilqr_solve(x0, init_U, goal, trajax_ilqr_kwargs or policy.trajax_ilqr_kwargs)
+    critic = dparams.view("critic_params") if loss_kind == 1 else None
+    loss, grad_sum = eng.bilevel_grad(B, loss_kind, desired=desired, critic=critic, sign=sign)
+    return loss, sol["grad"], grad_sum, sol["iterations"]

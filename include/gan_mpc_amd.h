@@ -128,6 +128,16 @@ int gmpc_ilqr_solve(gmpc_ctx* ctx, int B, const float* x0, const float* U_init, 
 int gmpc_bilevel_grad(gmpc_ctx* ctx, int B, int loss_kind, const float* desired,
                       const float* critic, float sign, float* loss, float* grad_sum, void* stream);
 
+/* a13/a16 only: the upper-level loss [B] at the solution held by the ctx, without the gradient
+ * (test-loss evaluation, norm/cost_trainer.py:13-21). */
+int gmpc_upper_loss(gmpc_ctx* ctx, int B, int loss_kind, const float* desired, const float* critic,
+                    float* loss, void* stream);
+
+/* a19: Polyak blend out = factor*prev + (1-factor)*cur over a flat range (norm/cost_trainer.py:88-92).
+ * out may alias prev or cur. */
+int gmpc_polyak(gmpc_ctx* ctx, long count, const float* prev, const float* cur, double factor,
+                float* out, void* stream);
+
 /* a14-a15: critic BCE loss and gradient (gan/js_policy.py:41-58, critic/nn.py:28-42).
  *   xseq [Bc][T+1][n], label [Bc] (+1 / -1), critic params
  *   -> loss_sum [1] (SUM over the batch of -log p), grad_sum [critic_count] (SUM over the batch). */

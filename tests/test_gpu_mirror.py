@@ -1,0 +1,197 @@
+"""The Python host mirror (reference protocol: models, policies, trainers) on the GPU, against the
+oracle driven the way the reference drives JAX."""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gan_mpc_oracle as orc
+import gpu_util as gu
+from gan_mpc_amd import optim, params as P, utils
+from gan_mpc_amd.expert.expert_model import TableExpert
+from gan_mpc_amd.gan import critic_trainer, js_policy
+from gan_mpc_amd.norm import cost_trainer, l2_policy
+
+pytestmark = pytest.mark.gpu
+CFG = os.path.join(os.path.dirname(__file__), "golden", "mirror_config.yaml")
+N, M = 4, 2
+
+
+def _build(policy_cls, ndata=24, seed=3):
+    config = utils.get_config(CFG)
+    T = config.mpc.horizon
+    cost, _ = utils.get_cost_model(config)
+    dynamics, _ = utils.get_dynamics_model(config, N)
+    critic, _ = utils.get_critic_model(config)
+    rng = np.random.default_rng(seed)
+    hist = rng.standard_normal((ndata, config.mpc.history + 1, N)).astype(np.float32)
+    goal = rng.standard_normal((ndata, T + 1, N)).astype(np.float32)
+    goal[:, 0] = hist[:, -1]
+    init_U = np.tanh(rng.standard_normal((ndata, T, M))).astype(np.float32)
+    Y = rng.standard_normal((ndata, T + 1, N)).astype(np.float32)
+    expert = TableExpert(goal, init_U)
+    kw = dict(config=config, cost_model=cost, dynamics_model=dynamics, expert_model=expert)
+    if policy_cls is js_policy.JS_MPC:
+        kw["critic_model"] = critic
+    policy = policy_cls(**kw)
+    mpc_weights = tuple(config.mpc.model.cost.weights.to_dict().values())
+    args = [mpc_weights, (config.seed, N), (config.seed, M), (True,)]
+    if policy_cls is js_policy.JS_MPC:
+        args.append((config.seed, N))
+    params = policy.init(*args)
+    # "trained-like" residual dynamics so that the few iLQR iterations are well conditioned
+    last = f"Dense_{config.mpc.model.dynamics.mlp.num_layers - 1}"
+    params["dynamics_params"]["params"][last]["kernel"] *= 0.1
+    return config, policy, params, dict(hist=hist, goal=goal, init_U=init_U, Y=Y)
+
+
+def _oracle_problem(params, data, idx, dtype):
+    pb = dict(dyn=P.tree_to_layers(params["dynamics_params"]),
+              cmlp=P.tree_to_layers(params["cost_params"]), mpc_w=params["mpc_weights"],
+              goal=data["goal"][idx], x0=data["hist"][idx, -1], U=data["init_U"][idx],
+              true_seq=data["Y"][idx])
+    if "critic_params" in params:
+        pb["critic"] = P.critic_tree_to_oracle(params["critic_params"])
+    return orc.cast_problem(pb, dtype)
+
+
+def test_params_dict_has_the_reference_keys():
+    _, policy, params, _ = _build(js_policy.JS_MPC)
+    assert set(params) == {"mpc_weights", "cost_params", "dynamics_params", "expert_params",
+                           "critic_params"}
+    assert params["mpc_weights"].dtype == np.float32 and params["mpc_weights"].shape == (3,)
+    assert list(params["cost_params"]["params"]) == ["Dense_0", "Dense_1", "Dense_2"]
+    assert params["dynamics_params"]["params"]["Dense_0"]["kernel"].shape == (N + M, 32)
+
+
+def test_get_optimal_values_is_the_trajax_7_tuple():
+    config, policy, params, data = _build(l2_policy.L2MPC)
+    policy.expert_model.select(np.array([2]))
+    out = policy.get_optimal_values(params, data["hist"][2])
+    assert len(out) == 7
+    X, U, obj, grad, adj, lqr, itr = out
+    T = config.mpc.horizon
+    assert X.shape == (T + 1, N) and U.shape == (T, M) and grad.shape == (T, M)
+    assert adj.shape == (T + 1, N) and lqr.shape == (T, N, N + M) and obj.dim() == 0
+    p64 = _oracle_problem(params, data, np.array([2]), np.float64)
+    r = orc.ilqr(p64["dyn"], p64["cmlp"], p64["mpc_w"], p64["goal"], p64["x0"], p64["U"])
+    assert abs(float(obj) - r[2][0]) / abs(r[2][0]) < 1e-3
+    policy.expert_model.select(np.array([2]))
+    a = policy.get_optimal_action(params, data["hist"][2])
+    assert a.shape == (M,)
+
+
+@pytest.mark.parametrize("cls", [l2_policy.L2MPC, js_policy.JS_MPC])
+def test_loss_and_grad_matches_oracle_batch_mean(cls):
+    config, policy, params, data = _build(cls)
+    policy.trajax_ilqr_kwargs["maxiter"] = 2
+    idx = np.arange(8)
+    policy.expert_model.select(idx)
+    loss, grads = policy.loss_and_grad(data["hist"][idx], params, (data["Y"][idx],))
+    res = {}
+    for dt in (np.float32, np.float64):
+        p = _oracle_problem(params, data, idx, dt)
+        l, g_mpc, g_cost, _ = orc.loss_and_grad(
+            p["dyn"], p["cmlp"], p["mpc_w"], p["goal"], p["x0"], p["U"],
+            loss="l2" if cls is l2_policy.L2MPC else "js", desired=p["true_seq"],
+            critic=p.get("critic"), kwargs={"maxiter": 2})
+        res[dt] = (l, gu.pack_grads_cost(g_mpc, g_cost))
+    gu.assert_parity("loss", float(loss), res[np.float32][0], res[np.float64][0], tol=1e-4, slack=10)
+    gu.assert_parity("grads", grads.cpu().numpy(), res[np.float32][1], res[np.float64][1], tol=1e-3,
+                     slack=10)
+
+
+def test_critic_loss_and_grad_is_batch_mean():
+    config, policy, params, data = _build(js_policy.JS_MPC)
+    xs = data["Y"][:10]
+    lab = np.array([1, -1] * 5, np.float32)
+    loss, grads = policy.critic_loss_and_grad(xs, lab, params)
+    cr = P.critic_tree_to_oracle(params["critic_params"])
+    l32, g32 = orc.critic_loss_and_grad(cr, xs, lab)
+    cr64 = orc.cast_problem(dict(c=cr), np.float64)["c"]
+    l64, g64 = orc.critic_loss_and_grad(cr64, xs.astype(np.float64), lab.astype(np.float64))
+    gu.assert_parity("loss", float(loss), l32, l64)
+    gu.assert_parity("grads", grads.cpu().numpy(), gu.pack_grads_critic(g32), gu.pack_grads_critic(g64))
+    # single-sample critic_loss as in the reference's vmap body
+    l1 = policy.critic_loss(xs[0], lab[0], params)
+    p = orc.sigmoid(orc.critic_forward(cr64, xs[:1].astype(np.float64)))
+    assert abs(float(l1) - float(-np.log(p[0]))) < 1e-5
+
+
+def test_cost_trainer_one_update_against_oracle_loop():
+    """cost_trainer.train == the reference loop (loss_and_grad -> clip+Adam -> Polyak) driven with
+    the oracle on the same minibatches."""
+    config, policy, params, data = _build(l2_policy.L2MPC)
+    policy.trajax_ilqr_kwargs["maxiter"] = 1
+    tc = config.mpc.train.cost
+    opt = optim.get_optimizer(list(params.keys()), tc.no_grads, tc.learning_rate)
+    assert opt.trainable_keys == ("mpc_weights", "cost_params")
+    dparams = policy.to_device_params(params)
+    opt_state = opt.init(dparams)
+    ntr = 16
+    train = (data["hist"][:ntr], data["Y"][:ntr])
+    test = (data["hist"][ntr:], data["Y"][ntr:])
+    out = cost_trainer.train((policy, opt), opt_state, dparams, (train, test), num_updates=1,
+                             batch_size=8, polyak_factor=tc.polyak_factor, key=7, id=0)
+    assert len(out) == 5   # (params, opt_state, train_losses, test_losses, exe_time) -- @timeit
+    new_params, opt_state, train_losses, test_losses, exe_time = out
+    assert opt_state["count"] == 2 and len(train_losses) == 1 and len(test_losses) == 1
+    # oracle loop on the same minibatch indices
+    rng = np.random.default_rng(7)
+    perm = rng.choice(ntr, size=(2, 8))
+    cost_flat = P.pack_mlp(params["cost_params"]).astype(np.float64)
+    theta = np.concatenate([params["mpc_weights"].astype(np.float64), cost_flat])
+    theta0 = theta.copy()
+    m = np.zeros_like(theta)
+    v = np.zeros_like(theta)
+    dims = P.mlp_dims(params["cost_params"])
+    losses = []
+    for k, p_idx in enumerate(perm):
+        cur = dict(params)
+        cur["mpc_weights"] = theta[:3]
+        cur["cost_params"] = P.unpack_mlp(theta[3:].astype(np.float32), dims)
+        p = _oracle_problem(cur, data, p_idx, np.float64)
+        p["mpc_w"] = theta[:3]
+        p["cmlp"] = [(W.astype(np.float64), b.astype(np.float64)) for W, b in
+                     P.tree_to_layers(cur["cost_params"])]
+        l, g_mpc, g_cost, _ = orc.loss_and_grad(p["dyn"], p["cmlp"], p["mpc_w"], p["goal"], p["x0"],
+                                                p["U"], loss="l2", desired=p["true_seq"],
+                                                kwargs={"maxiter": 1})
+        theta, m, v = orc.adam_clip_step(theta, gu.pack_grads_cost(g_mpc, g_cost), m, v, k + 1,
+                                         tc.learning_rate)
+        losses.append(l)
+    theta = orc.polyak(theta0, theta, tc.polyak_factor)
+    got = new_params.flat[:theta.size].cpu().numpy()
+    assert abs(train_losses[0] - np.mean(losses)) / abs(np.mean(losses)) < 1e-3
+    # Adam's first steps are ~ lr*sign(g): compare the parameter displacement
+    disp_ref, disp_got = theta - theta0, got - theta0
+    big = np.abs(disp_ref) > 0.5 * np.abs(disp_ref).max()
+    assert np.abs(disp_got[big] - disp_ref[big]).max() < 0.05 * np.abs(disp_ref).max()
+    # dynamics parameters: zero gradient, so only the Polyak blend 0.9*x + 0.1*x touches
+    # them, as in the reference (cost_trainer.py:88-92 blends every leaf): equal up to one rounding
+    np.testing.assert_allclose(new_params.view("dynamics_params").cpu().numpy(),
+                               P.pack_mlp(params["dynamics_params"]), rtol=2.5e-7, atol=0)
+
+
+def test_critic_trainer_runs_and_learns():
+    config, policy, params, data = _build(js_policy.JS_MPC)
+    policy.trajax_ilqr_kwargs["maxiter"] = 2
+    tc = config.mpc.train.critic
+    opt = optim.get_optimizer(list(params.keys()), tc.no_grads, 1e-2)
+    assert opt.trainable_keys == ("critic_params",)
+    dparams = policy.to_device_params(params)
+    before = dparams.view("critic_params").clone()
+    other = dparams.flat[:dparams.offsets["critic_params"]].clone()
+    opt_state = opt.init(dparams)
+    ntr = 16
+    ds = ((data["hist"][:ntr], data["Y"][:ntr]), (data["hist"][ntr:], data["Y"][ntr:]))
+    new_params, opt_state, tl, te, exe = critic_trainer.train(
+        (policy, opt), opt_state, dparams, ds, num_updates=3, batch_size=8, key=1, id=0)
+    assert len(tl) == 3 and len(te) == 3 and np.isfinite(tl).all() and np.isfinite(te).all()
+    assert tl[-1] < tl[0]                      # the critic separates true from rolled-out sequences
+    assert not torch.equal(before, new_params.view("critic_params"))
+    assert torch.equal(other, new_params.flat[:new_params.offsets["critic_params"]])
+    tree = new_params.to_tree()
+    assert set(tree["critic_params"]["params"]) >= {"ScanOptimizedLSTMCell_0", "Dense_0", "Dense_1"}

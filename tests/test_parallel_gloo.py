@@ -1,0 +1,83 @@
+"""N > 1 host logic on CPU (gloo, world_size 2): trajectory sharding and the single all-reduce of
+the packed [loss_sum | grad_sum] buffer reproduce the single-process batch mean."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import gan_mpc_oracle as orc
+from gan_mpc_amd import parallel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, B, out):
+    for p in (ROOT, os.path.join(ROOT, "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import gan_mpc_oracle as orc_  # noqa: F401
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pb = orc.make_problem(4, 2, 5, B, seed=9, lstm_features=8, dyn_hidden=(12,),
+                              cost_hidden=(10,), cost_fout=3)
+        lo, hi = parallel.shard_range(B)
+        label = np.where(np.arange(B) % 2 == 0, 1.0, -1.0).astype(np.float32)
+        # this rank's partial SUMS (what gmpc_critic_loss_grad returns), from the oracle
+        n_loc = hi - lo
+        l, g = orc.critic_loss_and_grad(pb["critic"], pb["true_seq"][lo:hi], label[lo:hi])
+        flat = np.concatenate([g["Wx"].ravel(), g["Wh"].ravel(), g["b"].ravel()]
+                              + [t.ravel() for Wb in g["head"] for t in Wb])
+        packed = torch.from_numpy(np.concatenate([[l * n_loc], flat * n_loc]).astype(np.float32))
+        parallel.allreduce_mean_from_sums(packed, n_loc)
+        out[rank] = (lo, hi, packed.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions_everything():
+    for count in (1, 7, 8, 1024, 1025):
+        for ws in (1, 2, 3, 8):
+            spans = [parallel.shard_range(count, r, ws) for r in range(ws)]
+            assert spans[0][0] == 0 and spans[-1][1] == count
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_mean():
+    packed = torch.tensor([10.0, 4.0, -6.0])
+    parallel.allreduce_mean_from_sums(packed, 4)
+    np.testing.assert_allclose(packed.numpy(), [2.5, 1.0, -1.5])
+
+
+def test_two_rank_allreduce_equals_single_process_batch_mean():
+    B, world = 7, 2          # ragged shards: 4 + 3
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, B, out), nprocs=world, join=True)
+    pb = orc.make_problem(4, 2, 5, B, seed=9, lstm_features=8, dyn_hidden=(12,),
+                          cost_hidden=(10,), cost_fout=3)
+    label = np.where(np.arange(B) % 2 == 0, 1.0, -1.0).astype(np.float32)
+    l, g = orc.critic_loss_and_grad(pb["critic"], pb["true_seq"], label)
+    flat = np.concatenate([g["Wx"].ravel(), g["Wh"].ravel(), g["b"].ravel()]
+                          + [t.ravel() for Wb in g["head"] for t in Wb])
+    want = np.concatenate([[l], flat])
+    assert (out[0][0], out[0][1], out[1][0], out[1][1]) == (0, 4, 4, 7)
+    np.testing.assert_array_equal(out[0][2], out[1][2])       # replicas stay identical
+    np.testing.assert_allclose(out[0][2], want, rtol=2e-5, atol=1e-7)   # N-GPU vs 1-GPU mean
