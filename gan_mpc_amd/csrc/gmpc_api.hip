@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <utility>
@@ -18,6 +19,10 @@ void gmpc_launch_masks(int, int, int, int, const MlpDesc&, const float*, const f
                        hipStream_t);
 int gmpc_launch_linearize(int, int, int, int, const MlpDesc&, const uint32_t*, const int*, float*,
                           hipStream_t);
+int gmpc_launch_linearize_mfma(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
+                               const int*, float*, hipStream_t);
+size_t gmpc_linpad_floats(const gmpc_shape*);
+void gmpc_linpad_prepare(const MlpDesc&, int, int, float*, size_t, LinPad*, hipStream_t);
 int gmpc_launch_terminal(int, int, int, const MlpDesc&, const float*, const float*, const int*,
                          float*, float*, hipStream_t);
 void gmpc_launch_riccati(const RiccatiArgs&, hipStream_t);
@@ -125,7 +130,9 @@ struct gmpc_ctx {
   // bound parameters
   const float* mpc_w = nullptr;
   MlpDesc dyn{}, cost{};
-  float *dynT = nullptr, *costT = nullptr;
+  float *dynT = nullptr, *costT = nullptr, *linpad = nullptr;
+  size_t linpad_floats = 0;
+  LinPad lp{};
   bool params_set = false;
   // trajectory workspace
   uint32_t *masks, *maskc;
@@ -214,6 +221,8 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
 #define A_(p, cnt) if (!rc) rc = dalloc(c, &c->p, (cnt))
   A_(dynT, mlp_count(s.dyn_layers, s.dyn_dims));
   A_(costT, mlp_count(s.cost_layers, s.cost_dims));
+  c->linpad_floats = gmpc_linpad_floats(&c->sh);
+  A_(linpad, c->linpad_floats);
   A_(masks, B * T * Lh * GMPC_MW);
   A_(maskc, B * T * Lh * GMPC_MW);
   A_(Xc, B * (T + 1) * n);
@@ -301,6 +310,7 @@ extern "C" int gmpc_set_params(gmpc_ctx* c, const float* mpc_w, const float* dyn
   bind_mlp(c->cost, c->sh.cost_layers, c->sh.cost_dims, cost, c->costT);
   transpose_mlp(c->dyn, s);
   transpose_mlp(c->cost, s);
+  gmpc_linpad_prepare(c->dyn, c->sh.n, c->sh.m, c->linpad, c->linpad_floats, &c->lp, s);
   HIP_TRY(hipGetLastError());
   c->params_set = true;
   return 0;
@@ -344,8 +354,17 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
   const gmpc_shape& sh = c->sh;
   {
     ProfScope ps(c, PROF_LINEARIZE, s);
-    if (gmpc_launch_linearize(B, sh.T, sh.n, sh.m, c->dyn, c->masks, active, AB, s) != 0)
-      return fail(GMPC_EINVAL, "linearize: unsupported row count for n=%d", sh.n);
+    // matrix-core chain; the VALU chain only serves shapes the MFMA tiling does not cover (or
+    // GMPC_LINEARIZE=valu, kept for A/B timing) -- both are HIP kernels of this library
+    static const bool force_valu = []() {
+      const char* e = getenv("GMPC_LINEARIZE");
+      return e && strcmp(e, "valu") == 0;
+    }();
+    if (force_valu ||
+        gmpc_launch_linearize_mfma(B, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active, AB, s) != 0) {
+      if (gmpc_launch_linearize(B, sh.T, sh.n, sh.m, c->dyn, c->masks, active, AB, s) != 0)
+        return fail(GMPC_EINVAL, "linearize: unsupported row count for n=%d", sh.n);
+    }
   }
   {
     ProfScope ps(c, PROF_TERMINAL, s);

@@ -164,3 +164,10 @@ struct CriticDesc {
   const float* b;            // [4F]
   MlpDesc head;              // dims[0] = F ... dims[L] = 1
 };
+
+// zero-padded weight copies read by the MFMA Jacobian chain (gmpc_linearize_mfma.hip)
+struct LinPad {
+  int NT, NTF;                          // column tiles of the hidden GEMMs / of the input GEMM
+  const float* WLP;                     // [dims[Lh]+2][n]            rows >= dims[Lh] are zero
+  const float* WTP[GMPC_MAX_LAYERS];    // l>=1: [dims[l+1]+2][32*NT]; l==0: [dims[1]+2][32*NTF]
+};

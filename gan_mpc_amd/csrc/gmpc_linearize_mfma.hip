@@ -1,0 +1,326 @@
+// Dynamics Jacobian chain on the matrix cores.
+//
+// For every sample (b,t) the n rows of  [A_t | B_t] - [I | 0] = W_L^T D_{L-1} W_{L-1}^T ... D_1 W_1^T
+// are rows of one big GEMM chain whose operands are the SHARED weight matrices: stacking the rows
+// of all B*T samples gives M = B*T*n rows (870,400 at the headline shape) against K = N = hidden
+// width.  That is a true dense contraction, so it runs on v_mfma_f32_32x32x2_f32 (exact fp32: the
+// result is the same k-ordered fmaf chain as the VALU kernel, MI355X_MICROARCH.md "FP32-input MFMA").
+//
+// One wavefront owns one 32-row tile for the whole chain:
+//   - A operand (rows x k): the previous layer's masked tile, kept in the wave's private LDS slab
+//     G[32][SK] (SK odd -> the column read of the A fragment and the row write of the accumulator
+//     are both bank-conflict free); the seed tile is built on the fly from W_L and the relu bits.
+//   - B operand (k x 32 columns): fragments of zero-padded transposed weights (K+2 rows x 32*NT
+//     columns, built once per gmpc_set_params) loaded straight from L2/L1 into registers, one k-step
+//     ahead of the MFMAs that consume them.  Padding makes the k-loop free of any conditional.
+//   - C: NT accumulators of 16 registers (32 x 32*NT columns), masked with the relu bits of the
+//     layer below in the epilogue and written back to G as the next A operand.
+// Waves never talk to each other: no workgroup barrier in the kernel.
+#include "gmpc_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+
+// out[o][i] = W[i][o] (W is (in,out) row-major) into a zero-initialised (rows x ldo) buffer
+__global__ void k_pad_transpose(int in, int out, const float* W, float* dst, int ldo) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= in * out) return;
+  const int i = e / out, o = e - i * out;
+  dst[(size_t)o * ldo + i] = W[e];
+}
+
+// One GEMM of the chain for one 32-row tile: acc[nt] += A[32 x Kp] * B[Kp x 32*NTT].
+// bp0 points at this lane's element of B row `half` (row stride NP floats, any address space);
+// afn(k0) returns this lane's A element of k-step k0 (k = k0 + half).  B/A of k-step k0+4 are
+// requested before the MFMAs of k-step k0 issue (three register sets, no copies), so two k-steps
+// of matrix work (2*NTT*64 cycles) cover the load latency even at one wave per SIMD.
+// Reads run up to 3 k-steps past Kp: the padded operands provide those rows/columns.
+template <int NTT, typename AF>
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ bp0, int NP, int Kp, AF afn,
+                                          f32x16 (&acc)[NTT]) {
+  float b0[NTT], b1[NTT], b2[NTT];
+  float a0, a1, a2;
+  const float* bp = bp0;
+#pragma unroll
+  for (int nt = 0; nt < NTT; ++nt) b0[nt] = bp[nt * 32];
+  a0 = afn(0);
+  bp += 2 * NP;
+#pragma unroll
+  for (int nt = 0; nt < NTT; ++nt) b1[nt] = bp[nt * 32];
+  a1 = afn(2);
+  int k0 = 0;
+  for (; k0 + 6 <= Kp; k0 += 6) {
+    bp += 2 * NP;
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) b2[nt] = bp[nt * 32];
+    a2 = afn(k0 + 4);
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
+    bp += 2 * NP;
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) b0[nt] = bp[nt * 32];
+    a0 = afn(k0 + 6);
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[nt], acc[nt], 0, 0, 0);
+    bp += 2 * NP;
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) b1[nt] = bp[nt * 32];
+    a1 = afn(k0 + 8);
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[nt], acc[nt], 0, 0, 0);
+  }
+  if (k0 < Kp) {
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
+    if (k0 + 2 < Kp) {
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[nt], acc[nt], 0, 0, 0);
+    }
+  }
+}
+
+#define GMPC_LIN_PADROWS 8   // zero rows after the last k row of every padded operand
+
+template <int NT, int NTF>
+__global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
+    int B, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
+    float* AB, int ntiles, int nsmax, int stage_wl, int stage_w1) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int SK = 32 * NT + 1;
+  constexpr int NP = 32 * NT;
+  constexpr int NPF = 32 * NTF;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Lh = dyn.L - 1;
+  const int nm = n + m;
+  const long Rtot = (long)B * T * n;
+  const size_t wave_bytes =
+      (size_t)(32 * SK + 8) * sizeof(float) + (size_t)Lh * nsmax * GMPC_MW * sizeof(uint32_t);
+  float* G = reinterpret_cast<float*>(smem + wave * wave_bytes);
+  uint32_t* mk = reinterpret_cast<uint32_t*>(G + 32 * SK + 8);   // [Lh][nsmax][MW]
+  // workgroup-shared copies of the two small operands (when they fit): W_L and the padded W_1^T
+  float* sh = reinterpret_cast<float*>(smem + (GMPC_THREADS / 64) * wave_bytes);
+  const int wl_floats = (dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;
+  const int w1_floats = (dyn.dims[1] + GMPC_LIN_PADROWS) * NPF;
+  float* wl_s = sh;
+  float* w1_s = sh + (stage_wl ? wl_floats : 0);
+  if (stage_wl)
+    for (int e = threadIdx.x; e < wl_floats; e += blockDim.x) wl_s[e] = lp.WLP[e];
+  if (stage_w1)
+    for (int e = threadIdx.x; e < w1_floats; e += blockDim.x) w1_s[e] = lp.WTP[0][e];
+  __syncthreads();   // the only workgroup barrier: after it the waves are independent
+  const int half = lane >> 5, l31 = lane & 31;
+
+  for (int tile = blockIdx.x * (GMPC_THREADS / 64) + wave; tile < ntiles;
+       tile += gridDim.x * (GMPC_THREADS / 64)) {
+    const long r0 = (long)tile * 32;
+    const int s_lo = (int)(r0 / n);
+    long rlast = r0 + 31;
+    if (rlast >= Rtot) rlast = Rtot - 1;
+    const int s_hi = (int)(rlast / n);
+    const int ns = s_hi - s_lo + 1;
+    if (active != nullptr) {
+      bool any = false;
+      for (int s = s_lo; s <= s_hi; ++s) any |= active[s / T] != 0;
+      if (!any) continue;
+    }
+    // ---- relu bit words of the tile's samples -> LDS
+    for (int e = lane; e < Lh * ns * GMPC_MW; e += 64) {
+      const int l = e / (ns * GMPC_MW), rem = e - l * ns * GMPC_MW;
+      const int si = rem / GMPC_MW, w = rem - si * GMPC_MW;
+      mk[(l * nsmax + si) * GMPC_MW + w] = masks[((size_t)(s_lo + si) * Lh + l) * GMPC_MW + w];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // this lane's A-operand row and its sample / output coordinate
+    long ra = r0 + l31;
+    if (ra >= Rtot) ra = Rtot - 1;
+    const int sa = (int)(ra / n) - s_lo;
+    const int ia = (int)(ra - (long)(sa + s_lo) * n);
+    // sample index of each accumulator row of this lane: row = (reg&3) + 8*(reg>>2) + 4*half
+    int sreg[16];
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      long rr = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+      if (rr >= Rtot) rr = Rtot - 1;
+      sreg[rg] = (int)(rr / n) - s_lo;
+    }
+    // A element of the seed tile: W_L[k][i_row] * relu bit(layer Lh-1, sample of row, k)
+    const uint32_t* mrow = mk + ((Lh - 1) * nsmax + sa) * GMPC_MW;
+    const float* wl_g = lp.WLP + (size_t)half * n + ia;
+    const float* wl_l = wl_s + half * n + ia;
+    auto a_seed_g = [&](int k0) -> float {
+      const int k = k0 + half;
+      const uint32_t w = mrow[(k >> 5) & (GMPC_MW - 1)];
+      const float v = wl_g[(size_t)k0 * n];
+      return ((w >> (k & 31)) & 1u) ? v : 0.f;
+    };
+    auto a_seed_l = [&](int k0) -> float {
+      const int k = k0 + half;
+      const uint32_t w = mrow[(k >> 5) & (GMPC_MW - 1)];
+      const float v = wl_l[k0 * n];
+      return ((w >> (k & 31)) & 1u) ? v : 0.f;
+    };
+    const float* aptr = G + l31 * SK + half;
+    auto a_slab = [&](int k0) -> float { return aptr[k0]; };
+
+    f32x16 acc[NT];
+    // ================= hidden GEMMs: l = Lh-1 (seeded from W_L) ... 1 =================
+    for (int l = Lh - 1; l >= 1; --l) {
+      const int K = dyn.dims[l + 1];
+      const int Kp = (K + 1) & ~1;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
+      const float* __restrict__ bp0 = lp.WTP[l] + (size_t)half * NP + l31;
+      if (l == Lh - 1) {
+        if (stage_wl) gemm_tile<NT>(bp0, NP, Kp, a_seed_l, acc);
+        else gemm_tile<NT>(bp0, NP, Kp, a_seed_g, acc);
+      } else {
+        gemm_tile<NT>(bp0, NP, Kp, a_slab, acc);
+      }
+      // ---- epilogue: mask with the relu bits of hidden layer l-1, write the next A operand.
+      // Columns >= dims[l] come out as exact zeros (zero-padded B, zero mask bits), which also
+      // provides the zero pad columns the next GEMM's read-ahead and an odd K need.
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          const int row = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+          const uint32_t w = mk[((l - 1) * nsmax + sreg[rg]) * GMPC_MW + nt];
+          const float v = ((w >> l31) & 1u) ? acc[nt][rg] : 0.f;
+          G[row * SK + nt * 32 + l31] = v;
+        }
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+    // ================= input GEMM (l = 0): N = n + m columns, NTF tiles =================
+    {
+      const int K = dyn.dims[1];
+      const int Kp = (K + 1) & ~1;
+      f32x16 acc0[NTF];
+#pragma unroll
+      for (int nt = 0; nt < NTF; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) acc0[nt][rg] = 0.f;
+      const float* bp_g = lp.WTP[0] + (size_t)half * NPF + l31;
+      const float* bp_l = w1_s + half * NPF + l31;
+      if (Lh == 1) {
+        // single hidden layer: the seed tile feeds the input GEMM directly
+        if (stage_w1) {
+          if (stage_wl) gemm_tile<NTF>(bp_l, NPF, Kp, a_seed_l, acc0);
+          else gemm_tile<NTF>(bp_l, NPF, Kp, a_seed_g, acc0);
+        } else {
+          if (stage_wl) gemm_tile<NTF>(bp_g, NPF, Kp, a_seed_l, acc0);
+          else gemm_tile<NTF>(bp_g, NPF, Kp, a_seed_g, acc0);
+        }
+      } else {
+        if (stage_w1) gemm_tile<NTF>(bp_l, NPF, Kp, a_slab, acc0);
+        else gemm_tile<NTF>(bp_g, NPF, Kp, a_slab, acc0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NTF; ++nt) {
+        const int c = nt * 32 + l31;
+        if (c < nm) {
+#pragma unroll
+          for (int rg = 0; rg < 16; ++rg) {
+            const long rr = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+            if (rr < Rtot) {
+              const int irow = (int)(rr - (long)(sreg[rg] + s_lo) * n);
+              AB[(size_t)rr * nm + c] = acc0[nt][rg] + (c == irow ? 1.0f : 0.0f);
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t gmpc_linpad_floats(const gmpc_shape* sh) {
+  const int L = sh->dyn_layers, Lh = L - 1;
+  int wmax = 1;
+  for (int l = 1; l < L; ++l) wmax = sh->dyn_dims[l] > wmax ? sh->dyn_dims[l] : wmax;
+  const int NT = (wmax + 31) / 32, NTF = (sh->n + sh->m + 31) / 32;
+  size_t f = (size_t)(sh->dyn_dims[Lh] + GMPC_LIN_PADROWS) * sh->n;
+  f += (size_t)(sh->dyn_dims[1] + GMPC_LIN_PADROWS) * 32 * NTF;
+  for (int l = 1; l < Lh; ++l) f += (size_t)(sh->dyn_dims[l + 1] + GMPC_LIN_PADROWS) * 32 * NT;
+  return f + 64;
+}
+
+// builds the padded copies; `pad` must hold gmpc_linpad_floats() floats
+void gmpc_linpad_prepare(const MlpDesc& dyn, int n, int m, float* pad, size_t pad_floats, LinPad* out,
+                         hipStream_t s) {
+  const int Lh = dyn.L - 1;
+  int wmax = 1;
+  for (int l = 1; l < dyn.L; ++l) wmax = dyn.dims[l] > wmax ? dyn.dims[l] : wmax;
+  out->NT = (wmax + 31) / 32;
+  out->NTF = (n + m + 31) / 32;
+  (void)hipMemsetAsync(pad, 0, pad_floats * sizeof(float), s);
+  float* p = pad;
+  // W_L: (dims[Lh] x n) row-major already is [k][i]; copy, padded rows stay zero
+  out->WLP = p;
+  (void)hipMemcpyAsync(p, dyn.W[Lh], (size_t)dyn.dims[Lh] * n * sizeof(float), hipMemcpyDeviceToDevice, s);
+  p += (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;
+  for (int l = 0; l < Lh; ++l) {
+    const int in = dyn.dims[l], outd = dyn.dims[l + 1];
+    const int ldo = 32 * (l == 0 ? out->NTF : out->NT);
+    out->WTP[l] = p;
+    const int cnt = in * outd;
+    hipLaunchKernelGGL(k_pad_transpose, dim3((cnt + 255) / 256), dim3(256), 0, s, in, outd, dyn.W[l],
+                       p, ldo);
+    p += (size_t)(outd + GMPC_LIN_PADROWS) * ldo;
+  }
+}
+
+template <int NT, int NTF>
+static int launch_mfma(int B, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
+                       const uint32_t* masks, const int* active, float* AB, hipStream_t s) {
+  const long Rtot = (long)B * T * n;
+  const int ntiles = (int)((Rtot + 31) / 32);
+  const int nsmax = 32 / n + 2;
+  const int Lh = dyn.L - 1;
+  const size_t wave_bytes = (size_t)(32 * (32 * NT + 1) + 8) * sizeof(float) +
+                            (size_t)Lh * nsmax * GMPC_MW * sizeof(uint32_t);
+  size_t lds = wave_bytes * (GMPC_THREADS / 64);
+  const size_t lds_max = 160 * 1024;
+  if (lds > lds_max) return -1;
+  // stage the two small operands in LDS when they fit (W_1^T first: its GEMM has one MFMA per
+  // k-step and is latency-bound from L2)
+  const size_t w1_bytes = (size_t)(dyn.dims[1] + GMPC_LIN_PADROWS) * 32 * NTF * sizeof(float);
+  const size_t wl_bytes = (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n * sizeof(float);
+  int stage_w1 = 0, stage_wl = 0;
+  if (lds + w1_bytes <= lds_max) { stage_w1 = 1; lds += w1_bytes; }
+  if (lds + wl_bytes <= lds_max) { stage_wl = 1; lds += wl_bytes; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linearize_mfma<NT, NTF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
+    attr_set = true;
+  }
+  int grid = (ntiles + 3) / 4;
+  if (grid > 256) grid = 256;   // one persistent workgroup per CU (LDS-limited to 1 anyway)
+  hipLaunchKernelGGL((k_linearize_mfma<NT, NTF>), dim3(grid), dim3(GMPC_THREADS), lds, s, B, T, n, m,
+                     dyn, lp, masks, active, AB, ntiles, nsmax, stage_wl, stage_w1);
+  return 0;
+}
+
+// returns 0 on launch, -1 if the shape does not fit this kernel (caller uses the VALU chain)
+int gmpc_launch_linearize_mfma(int B, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
+                               const uint32_t* masks, const int* active, float* AB, hipStream_t s) {
+#define GMPC_LM(a, b) \
+  if (lp.NT == a && lp.NTF == b) return launch_mfma<a, b>(B, T, n, m, dyn, lp, masks, active, AB, s);
+  GMPC_LM(1, 1) GMPC_LM(2, 1) GMPC_LM(3, 1) GMPC_LM(4, 1) GMPC_LM(5, 1) GMPC_LM(6, 1) GMPC_LM(7, 1)
+  GMPC_LM(8, 1) GMPC_LM(2, 2) GMPC_LM(3, 2) GMPC_LM(4, 2) GMPC_LM(5, 2) GMPC_LM(6, 2) GMPC_LM(7, 2)
+  GMPC_LM(8, 2) GMPC_LM(3, 3) GMPC_LM(4, 3) GMPC_LM(7, 3) GMPC_LM(8, 3)
+#undef GMPC_LM
+  return -1;
+}
