@@ -213,15 +213,21 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_terminal(int B, int T, int n, 
 // ------------------------------------------------------------------------------------------------
 // k_riccati: one wavefront per trajectory walks t = T-1 .. 0 with P, p and the adjoint in LDS and
 // emits the LQR gains (K_t, k_t), the control gradient g_t and the adjoints lambda_t.
+// (GMPC_RIC_THREADS threads per trajectory)
 // mode 0 : iLQR step (trajax lqr_step with delta = 1e-8, Cholesky; q_t, r_t from the cost)
 // mode 1 : bilevel Hessian solve (no regulariser; linear term r~_t = -Bvec_t, q~ = 0); then a forward
 //          tangent roll writes H_t = dU_t and dX_t  (oracle hessian_solve).
 // ------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(64) void k_riccati(RiccatiArgs a) {
+#define GMPC_RIC_THREADS 256
+// N_, M_ > 0: state / action sizes known at compile time (inner products fully unrolled, so their
+// LDS reads issue back to back instead of one dependent round trip per k); 0: run-time sizes.
+template <int N_, int M_>
+__global__ __launch_bounds__(GMPC_RIC_THREADS) void k_riccati(RiccatiArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n = a.n, m = a.m, T = a.T, nm = n + m;
-  const int lane = threadIdx.x;
+  const int n = N_ > 0 ? N_ : a.n, m = M_ > 0 ? M_ : a.m, T = a.T, nm = n + m;
+  const int lane = threadIdx.x;   // thread index within the trajectory's workgroup
+  constexpr int NTH = GMPC_RIC_THREADS;
   const int b = blockIdx.x;
   if (a.active != nullptr && a.active[b] == 0) return;
   float* ABs = reinterpret_cast<float*>(smem);   // n x nm
@@ -247,8 +253,8 @@ __global__ __launch_bounds__(64) void k_riccati(RiccatiArgs a) {
   const float al = GMPC_ALPHA;
   const float delta = a.mode == 0 ? 1e-8f : 0.f;
 
-  for (int e = lane; e < n * n; e += 64) P[e] = a.QT[(size_t)b * n * n + e];
-  for (int i = lane; i < n; i += 64) {
+  for (int e = lane; e < n * n; e += NTH) P[e] = a.QT[(size_t)b * n * n + e];
+  for (int i = lane; i < n; i += NTH) {
     const float q = a.qT[(size_t)b * n + i];
     pv[i] = a.mode == 0 ? q : 0.f;
     lam[i] = q;
@@ -259,81 +265,81 @@ __global__ __launch_bounds__(64) void k_riccati(RiccatiArgs a) {
 
   for (int t = T - 1; t >= 0; --t) {
     const size_t bt = (size_t)b * T + t;
-    for (int e = lane; e < n * nm; e += 64) ABs[e] = a.AB[bt * n * nm + e];
-    for (int i = lane; i < n; i += 64)
+    for (int e = lane; e < n * nm; e += NTH) ABs[e] = a.AB[bt * n * nm + e];
+    for (int i = lane; i < n; i += NTH)
       dv[i] = a.X[((size_t)b * (T + 1) + t) * n + i] - a.goal[((size_t)b * (T + 1) + t) * n + i];
-    for (int j = lane; j < m; j += 64) uv[j] = a.U[bt * m + j];
+    for (int j = lane; j < m; j += NTH) uv[j] = a.U[bt * m + j];
     __syncthreads();
     float dd = 0.f, uu = 0.f;
-    for (int i = 0; i < n; ++i) dd = fmaf(dv[i], dv[i], dd);
-    for (int j = 0; j < m; ++j) uu = fmaf(uv[j], uv[j], uu);
+    _Pragma("unroll") for (int i = 0; i < n; ++i) dd = fmaf(dv[i], dv[i], dd);
+    _Pragma("unroll") for (int j = 0; j < m; ++j) uu = fmaf(uv[j], uv[j], uu);
     const float s = sqrtf(dd + al * al), su = sqrtf(uu + al * al);
     const float is = 1.f / s, is3 = 1.f / (s * s * s), isu = 1.f / su, isu3 = 1.f / (su * su * su);
     // q_t, r_t ; adjoint / gradient (iLQR) ; linear terms
-    for (int i = lane; i < n; i += 64) qv[i] = w1 * dv[i] / s;
-    for (int j = lane; j < m; j += 64) rv[j] = w0 * uv[j] / su;
+    for (int i = lane; i < n; i += NTH) qv[i] = w1 * dv[i] / s;
+    for (int j = lane; j < m; j += NTH) rv[j] = w0 * uv[j] / su;
     __syncthreads();
     if (a.mode == 0) {
       // g_t = r_t + B^T lam ; lam_t = q_t + A^T lam
-      for (int j = lane; j < m; j += 64) {
+      for (int j = lane; j < m; j += NTH) {
         float g = 0.f;
-        for (int i = 0; i < n; ++i) g = fmaf(ABs[i * nm + n + j], lam[i], g);
+        _Pragma("unroll") for (int i = 0; i < n; ++i) g = fmaf(ABs[i * nm + n + j], lam[i], g);
         g = rv[j] + g;
         gn2 = fmaf(g, g, gn2);
         if (a.grad) a.grad[bt * m + j] = g;
       }
-      for (int c = lane; c < n; c += 64) {
+      for (int c = lane; c < n; c += NTH) {
         float v = 0.f;
-        for (int i = 0; i < n; ++i) v = fmaf(ABs[i * nm + c], lam[i], v);
+        _Pragma("unroll") for (int i = 0; i < n; ++i) v = fmaf(ABs[i * nm + c], lam[i], v);
         tv[c] = qv[c] + v;
       }
       __syncthreads();
-      for (int c = lane; c < n; c += 64) {
+      for (int c = lane; c < n; c += NTH) {
         lam[c] = tv[c];
         if (a.adj) a.adj[((size_t)b * (T + 1) + t) * n + c] = tv[c];
       }
     }
     // AtP = A^T P ; BtP = B^T P
-    for (int e = lane; e < n * n; e += 64) {
+    for (int e = lane; e < n * n; e += NTH) {
       const int i = e / n, j = e - i * n;
       float v = 0.f;
-      for (int k = 0; k < n; ++k) v = fmaf(ABs[k * nm + i], P[k * n + j], v);
+      _Pragma("unroll") for (int k = 0; k < n; ++k) v = fmaf(ABs[k * nm + i], P[k * n + j], v);
       AtP[e] = v;
     }
-    for (int e = lane; e < m * n; e += 64) {
+    for (int e = lane; e < m * n; e += NTH) {
       const int i = e / n, j = e - i * n;
       float v = 0.f;
-      for (int k = 0; k < n; ++k) v = fmaf(ABs[k * nm + n + i], P[k * n + j], v);
+      _Pragma("unroll") for (int k = 0; k < n; ++k) v = fmaf(ABs[k * nm + n + i], P[k * n + j], v);
       BtP[e] = v;
     }
     __syncthreads();
     // T1 = AtP A ; Hm = BtP A (+ M^T = 0) ; G = sym(R + BtP B) ; h = r + B^T p
-    for (int e = lane; e < n * n; e += 64) {
+    for (int e = lane; e < n * n; e += NTH) {
       const int i = e / n, j = e - i * n;
       float v = 0.f;
-      for (int k = 0; k < n; ++k) v = fmaf(AtP[i * n + k], ABs[k * nm + j], v);
+      _Pragma("unroll") for (int k = 0; k < n; ++k) v = fmaf(AtP[i * n + k], ABs[k * nm + j], v);
       T1[e] = v;
     }
-    for (int e = lane; e < m * n; e += 64) {
+    for (int e = lane; e < m * n; e += NTH) {
       const int i = e / n, j = e - i * n;
       float v = 0.f;
-      for (int k = 0; k < n; ++k) v = fmaf(BtP[i * n + k], ABs[k * nm + j], v);
+      _Pragma("unroll") for (int k = 0; k < n; ++k) v = fmaf(BtP[i * n + k], ABs[k * nm + j], v);
       Hm[e] = v;
     }
-    for (int e = lane; e < m * m; e += 64) {
+    for (int e = lane; e < m * m; e += NTH) {
       const int i = e / m, j = e - i * m;
       float v = 0.f;
-      for (int k = 0; k < n; ++k) v = fmaf(BtP[i * n + k], ABs[k * nm + n + j], v);
+      _Pragma("unroll") for (int k = 0; k < n; ++k) v = fmaf(BtP[i * n + k], ABs[k * nm + n + j], v);
       const float Rij = w0 * ((i == j ? isu : 0.f) - uv[i] * uv[j] * isu3);
       Lc[e] = Rij + v;  // unsymmetrised, staged in Lc
     }
-    for (int j = lane; j < m; j += 64) {
+    for (int j = lane; j < m; j += NTH) {
       float v = 0.f;
-      for (int i = 0; i < n; ++i) v = fmaf(ABs[i * nm + n + j], pv[i], v);
+      _Pragma("unroll") for (int i = 0; i < n; ++i) v = fmaf(ABs[i * nm + n + j], pv[i], v);
       hv[j] = (a.mode == 0 ? rv[j] : -a.Bvec[bt * m + j]) + v;
     }
     __syncthreads();
-    for (int e = lane; e < m * m; e += 64) {
+    for (int e = lane; e < m * m; e += NTH) {
       const int i = e / m, j = e - i * m;
       G[e] = (Lc[e] + Lc[j * m + i]) * 0.5f;
     }
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(64) void k_riccati(RiccatiArgs a) {
         }
       }
       __syncthreads();
-      for (int c = lane; c <= n; c += 64) {
+      for (int c = lane; c <= n; c += NTH) {
         // column c of the right-hand side: H[:,c] for c<n, h for c==n
         for (int i = 0; i < m; ++i) {
           float v = c < n ? Hm[i * n + c] : hv[i];
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(64) void k_riccati(RiccatiArgs a) {
         }
       }
       __syncthreads();
-      for (int c = lane; c <= n; c += 64) {
+      for (int c = lane; c <= n; c += NTH) {
         for (int i = m - 1; i >= 0; --i) {
           float v = Kk[i * (n + 1) + c];
           for (int k = i + 1; k < m; ++k) v -= Lc[i * m + k] * Kk[k * (n + 1) + c];
@@ -407,59 +413,63 @@ __global__ __launch_bounds__(64) void k_riccati(RiccatiArgs a) {
     __syncthreads();
     // outputs K_t, k_t ; HGK = H + G K
     if (a.K)
-      for (int e = lane; e < m * n; e += 64) {
+      for (int e = lane; e < m * n; e += NTH) {
         const int i = e / n, j = e - i * n;
         a.K[bt * m * n + e] = Kk[i * (n + 1) + j];
       }
     if (a.k)
-      for (int j = lane; j < m; j += 64) a.k[bt * m + j] = Kk[j * (n + 1) + n];
-    for (int e = lane; e < m * n; e += 64) {
+      for (int j = lane; j < m; j += NTH) a.k[bt * m + j] = Kk[j * (n + 1) + n];
+    for (int e = lane; e < m * n; e += NTH) {
       const int i = e / n, j = e - i * n;
       float v = 0.f;
-      for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], Kk[k * (n + 1) + j], v);
+      _Pragma("unroll") for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], Kk[k * (n + 1) + j], v);
       HGK[e] = Hm[e] + v;
     }
     __syncthreads();
     // S = Q + sym(T1) + HGK^T K + K^T H   (staged in AtP), P = sym(S)
-    for (int e = lane; e < n * n; e += 64) {
+    for (int e = lane; e < n * n; e += NTH) {
       const int i = e / n, j = e - i * n;
       const float Qij = w1 * ((i == j ? is : 0.f) - dv[i] * dv[j] * is3);
       float v1 = 0.f, v2 = 0.f;
-      for (int k = 0; k < m; ++k) {
+      _Pragma("unroll") for (int k = 0; k < m; ++k) {
         v1 = fmaf(HGK[k * n + i], Kk[k * (n + 1) + j], v1);
         v2 = fmaf(Kk[k * (n + 1) + i], Hm[k * n + j], v2);
       }
       AtP[e] = ((Qij + (T1[e] + T1[j * n + i]) * 0.5f) + v1) + v2;
     }
     // p = q + A^T p + HGK^T k + K^T h
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += NTH) {
       float v = 0.f, v1 = 0.f, v2 = 0.f;
-      for (int k = 0; k < n; ++k) v = fmaf(ABs[k * nm + i], pv[k], v);
-      for (int k = 0; k < m; ++k) {
+      _Pragma("unroll") for (int k = 0; k < n; ++k) v = fmaf(ABs[k * nm + i], pv[k], v);
+      _Pragma("unroll") for (int k = 0; k < m; ++k) {
         v1 = fmaf(HGK[k * n + i], Kk[k * (n + 1) + n], v1);
         v2 = fmaf(Kk[k * (n + 1) + i], hv[k], v2);
       }
       tv[i] = (((a.mode == 0 ? qv[i] : 0.f) + v) + v1) + v2;
     }
     __syncthreads();
-    for (int e = lane; e < n * n; e += 64) {
+    for (int e = lane; e < n * n; e += NTH) {
       const int i = e / n, j = e - i * n;
       P[e] = (AtP[e] + AtP[j * n + i]) * 0.5f;
     }
-    for (int i = lane; i < n; i += 64) pv[i] = tv[i];
+    for (int i = lane; i < n; i += NTH) pv[i] = tv[i];
     __syncthreads();
   }
 
   if (a.mode == 0) {
     if (a.cont != nullptr) {
-      gn2 = wave_sum(gn2);
       float un2 = 0.f;
-      for (int e = lane; e < T * m; e += 64) {
+      for (int e = lane; e < T * m; e += NTH) {
         const float u = a.U[(size_t)b * T * m + e];
         un2 = fmaf(u, u, un2);
       }
+      gn2 = wave_sum(gn2);
       un2 = wave_sum(un2);
+      if ((lane & 63) == 0) { tv[lane >> 6] = gn2; tv[NTH / 64 + (lane >> 6)] = un2; }
+      __syncthreads();
       if (lane == 0) {
+        gn2 = 0.f; un2 = 0.f;
+        for (int w = 0; w < NTH / 64; ++w) { gn2 += tv[w]; un2 += tv[NTH / 64 + w]; }
         float gn = sqrtf(gn2);
         if (isnan(gn)) gn = INFINITY;
         const float aobj = fabsf(a.obj[b]) + 1.0f;
@@ -477,26 +487,26 @@ __global__ __launch_bounds__(64) void k_riccati(RiccatiArgs a) {
   }
   // mode 1: forward tangent roll  dU_t = k_t + K_t dX_t ; dX_{t+1} = A dX_t + B dU_t
   // (gains were written to a.K / a.k by the sweep above; the caller passes scratch buffers)
-  for (int i = lane; i < n; i += 64) { pv[i] = 0.f; a.dX[(size_t)b * (T + 1) * n + i] = 0.f; }
+  for (int i = lane; i < n; i += NTH) { pv[i] = 0.f; a.dX[(size_t)b * (T + 1) * n + i] = 0.f; }
   __syncthreads();
   for (int t = 0; t < T; ++t) {
     const size_t bt = (size_t)b * T + t;
-    for (int e = lane; e < n * nm; e += 64) ABs[e] = a.AB[bt * n * nm + e];
-    for (int j = lane; j < m; j += 64) {
+    for (int e = lane; e < n * nm; e += NTH) ABs[e] = a.AB[bt * n * nm + e];
+    for (int j = lane; j < m; j += NTH) {
       float v = a.k[bt * m + j];
-      for (int i = 0; i < n; ++i) v = fmaf(a.K[bt * m * n + j * n + i], pv[i], v);
+      _Pragma("unroll") for (int i = 0; i < n; ++i) v = fmaf(a.K[bt * m * n + j * n + i], pv[i], v);
       uv[j] = v;
       a.Hout[bt * m + j] = v;
     }
     __syncthreads();
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += NTH) {
       float v = 0.f;
-      for (int k = 0; k < n; ++k) v = fmaf(ABs[i * nm + k], pv[k], v);
-      for (int k = 0; k < m; ++k) v = fmaf(ABs[i * nm + n + k], uv[k], v);
+      _Pragma("unroll") for (int k = 0; k < n; ++k) v = fmaf(ABs[i * nm + k], pv[k], v);
+      _Pragma("unroll") for (int k = 0; k < m; ++k) v = fmaf(ABs[i * nm + n + k], uv[k], v);
       tv[i] = v;
     }
     __syncthreads();
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += NTH) {
       pv[i] = tv[i];
       a.dX[((size_t)b * (T + 1) + t + 1) * n + i] = tv[i];
     }
@@ -506,7 +516,7 @@ __global__ __launch_bounds__(64) void k_riccati(RiccatiArgs a) {
 
 size_t gmpc_riccati_lds_bytes(int n, int m) {
   const size_t f = (size_t)n * (n + m) + 3 * (size_t)n * n + 3 * (size_t)m * n + (size_t)m * (n + 1) +
-                   2 * (size_t)m * m + 5 * (size_t)n + 3 * (size_t)m;
+                   2 * (size_t)m * m + 5 * (size_t)n + 3 * (size_t)m + 16;
   return f * sizeof(float);
 }
 
@@ -559,5 +569,9 @@ int gmpc_launch_terminal(int B, int T, int n, const MlpDesc& cm, const float* mp
 }
 
 void gmpc_launch_riccati(const RiccatiArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(k_riccati, dim3(a.B), dim3(64), gmpc_riccati_lds_bytes(a.n, a.m), s, a);
+  const size_t lds = gmpc_riccati_lds_bytes(a.n, a.m);
+  const dim3 g(a.B), b(GMPC_RIC_THREADS);
+  if (a.n == 17 && a.m == 6) hipLaunchKernelGGL((k_riccati<17, 6>), g, b, lds, s, a);
+  else if (a.n == 3 && a.m == 1) hipLaunchKernelGGL((k_riccati<3, 1>), g, b, lds, s, a);
+  else hipLaunchKernelGGL((k_riccati<0, 0>), g, b, lds, s, a);
 }
