@@ -35,7 +35,7 @@ void gmpc_launch_head(int, const CriticDesc&, int, const float*, const float*, f
 void gmpc_launch_lstm_bwd(int, const CriticDesc&, const float*, const float*, const float*, float*,
                           float*, hipStream_t);
 void gmpc_launch_wgrad(int, int, int, const float*, int, const float*, int, float*, float*, int,
-                       float*, int, hipStream_t);
+                       float*, int, hipStream_t, long, bool);
 void gmpc_launch_sum(int, const float*, float*, int, hipStream_t);
 void gmpc_launch_adam(long, float*, const float*, float*, float*, float, int, double, double, double,
                       double, double, float*, hipStream_t);
@@ -249,7 +249,7 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
   A_(dX, B * (T + 1) * n);
   A_(gmpc, B * 3);
   A_(cact, 2 * B * c->cstride);
-  A_(cdel, 2 * B * c->cstride);
+  A_(cdel, (2 * B + 8) * c->cstride);
   A_(bl_loss, B);
   // critic
   long wmax = 0;
@@ -268,9 +268,9 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
     A_(cs, Bc * T1 * F);
     A_(hp, Bc * T1 * F);
     A_(hT, Bc * F);
-    A_(dz, Bc * T1 * 4 * F);
+    A_(dz, (Bc * T1 + 8) * 4 * F);
     A_(hacts, Bc * c->hstride);
-    A_(hdels, Bc * c->hstride);
+    A_(hdels, (Bc + 8) * c->hstride);
     A_(dhT, Bc * F);
     A_(cscore, Bc);
     A_(closs, Bc);
@@ -282,9 +282,16 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
     }
   }
   c->wpart_floats = 256 * wmax;
+  if (c->wpart_floats < (12L << 20)) c->wpart_floats = 12L << 20;
   A_(wpart, c->wpart_floats);
   A_(scratch, 1024);
 #undef A_
+  // B operands of the MFMA weight-gradient GEMM are read a few rows past the end: keep them finite
+  if (!rc && c->cdel) (void)hipMemset(c->cdel, 0, (2 * B + 8) * c->cstride * sizeof(float));
+  if (!rc && s.lstm_features > 0) {
+    (void)hipMemset(c->dz, 0, ((size_t)2 * B * (T + 1) + 8) * 4 * s.lstm_features * sizeof(float));
+    (void)hipMemset(c->hdels, 0, ((size_t)2 * B + 8) * c->hstride * sizeof(float));
+  }
   if (rc) {
     gmpc_destroy(c);
     return rc;
@@ -517,14 +524,14 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     float* gWx = grad_sum;
     float* gWh = gWx + (long)n * G4;
     float* gb = gWh + (long)F * G4;
-    gmpc_launch_wgrad(rows, n, G4, xseq, n, c->dz, G4, gWx, nullptr, 0, c->wpart, 256, s);
-    gmpc_launch_wgrad(rows, F, G4, c->hp, F, c->dz, G4, gWh, gb, rows, c->wpart, 256, s);
+    gmpc_launch_wgrad(rows, n, G4, xseq, n, c->dz, G4, gWx, nullptr, 0, c->wpart, 256, s, c->wpart_floats, true);
+    gmpc_launch_wgrad(rows, F, G4, c->hp, F, c->dz, G4, gWh, gb, rows, c->wpart, 256, s, c->wpart_floats, true);
     float* gh = gb + G4;
     int aoff = 0, doff = 0;
     for (int l = 0; l < sh.head_layers; ++l) {
       const int M = sh.head_dims[l], N = sh.head_dims[l + 1];
       gmpc_launch_wgrad(Bc, M, N, c->hacts + aoff, c->hstride, c->hdels + doff, c->hstride, gh,
-                        gh + (long)M * N, Bc, c->wpart, 256, s);
+                        gh + (long)M * N, Bc, c->wpart, 256, s, c->wpart_floats, true);
       gh += (long)M * N + N;
       aoff += M;
       doff += N;
@@ -619,13 +626,13 @@ extern "C" int gmpc_bilevel_grad(gmpc_ctx* c, int B, int loss_kind, const float*
   gmpc_launch_costvjp(B, T, n, m, c->cost, c->mpc_w, sign, c->Xs, c->Us, c->goals, c->Hout, c->dX,
                       c->gmpc, c->cact, c->cdel, c->cstride, s);
   // sums over the batch: mpc_w (3 columns of gmpc) and the cost layers
-  gmpc_launch_wgrad(B, 1, 3, c->gmpc, 0, c->gmpc, 3, c->scratch + 512, grad_sum, B, c->wpart, 256, s);
+  gmpc_launch_wgrad(B, 1, 3, c->gmpc, 0, c->gmpc, 3, c->scratch + 512, grad_sum, B, c->wpart, 256, s, c->wpart_floats, false);
   float* g = grad_sum + 3;
   int aoff = 0, doff = 0;
   for (int l = 0; l < sh.cost_layers; ++l) {
     const int M = sh.cost_dims[l], N = sh.cost_dims[l + 1];
     gmpc_launch_wgrad(2 * B, M, N, c->cact + aoff, c->cstride, c->cdel + doff, c->cstride, g,
-                      g + (long)M * N, B, c->wpart, 256, s);
+                      g + (long)M * N, B, c->wpart, 256, s, c->wpart_floats, true);
     g += (long)M * N + N;
     aoff += M;
     doff += N;

@@ -319,13 +319,28 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_wgrad(int rows, int M, int N, 
     }
 }
 
-// out[e] = sum_sp part[sp][e] in split order (deterministic)
-__global__ void k_reduce_splits(int count, int nsplit, const float* part, float* out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= count) return;
-  float s = 0.f;
-  for (int sp = 0; sp < nsplit; ++sp) s += part[(size_t)sp * count + e];
-  out[e] = s;
+// out[e] = sum_sp part[sp][e], deterministic: 64 elements per block, the splits are shared by 4
+// thread groups, each keeping 8 independent partial sums (so 8 loads are in flight per thread);
+// the fixed combination order makes the result run-to-run identical.
+__global__ __launch_bounds__(256) void k_reduce_splits(int count, int nsplit, const float* part,
+                                                       float* out) {
+  __shared__ float sh[4][64];
+  const int el = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + el;
+  const int q = (nsplit + 3) / 4;
+  const int s0 = seg * q, s1 = min(nsplit, s0 + q);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (e < count) {
+    int sp = s0;
+    for (; sp + 8 <= s1; sp += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += part[(size_t)(sp + u) * count + e];
+    }
+    for (; sp < s1; ++sp) a[0] += part[(size_t)sp * count + e];
+  }
+  sh[seg][el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (seg == 0 && e < count) out[e] = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
 }
 
 // Single-block sum of `count` floats (fixed order: thread-strided partials, then tree in LDS).
@@ -437,9 +452,17 @@ void gmpc_launch_lstm_bwd(int Bc, const CriticDesc& cd, const float* gates, cons
 
 // C[M][N] = sum_r A[r][:M]^T B[r][:N]; colsum[N] = sum_{r < cs_rows} B[r][:N] (optional).
 // part must hold nsplit*(M*N + N) floats.
+bool gmpc_launch_wgrad_mfma(int rows, int M, int N, const float* A, int lda, const float* Bm, int ldb,
+                            float* C, float* colsum, int cs_rows, float* part, long part_floats,
+                            hipStream_t s);
+
+// part holds part_floats floats (at least max_split*(M*N + N)); mfma_ok: B has >= 8 zero pad rows
 void gmpc_launch_wgrad(int rows, int M, int N, const float* A, int lda, const float* Bm, int ldb,
                        float* C, float* colsum, int cs_rows, float* part, int max_split,
-                       hipStream_t s) {
+                       hipStream_t s, long part_floats, bool mfma_ok) {
+  if (mfma_ok && gmpc_launch_wgrad_mfma(rows, M, N, A, lda, Bm, ldb, C, colsum, cs_rows, part,
+                                        part_floats, s))
+    return;
   int nsplit = (rows + 511) / 512;
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;
@@ -450,10 +473,10 @@ void gmpc_launch_wgrad(int rows, int M, int N, const float* A, int lda, const fl
   float* cspart = colsum ? part + (size_t)nsplit * M * N : nullptr;
   hipLaunchKernelGGL(k_wgrad, dim3((M + 63) / 64, (N + 63) / 64, nsplit), dim3(GMPC_THREADS), 0, s,
                      rows, M, N, A, lda, Bm, ldb, rps, cpart, cspart, cs_rows);
-  hipLaunchKernelGGL(k_reduce_splits, dim3((M * N + 255) / 256), dim3(256), 0, s, M * N, nsplit, cpart,
+  hipLaunchKernelGGL(k_reduce_splits, dim3((M * N + 63) / 64), dim3(256), 0, s, M * N, nsplit, cpart,
                      C);
   if (colsum)
-    hipLaunchKernelGGL(k_reduce_splits, dim3((N + 255) / 256), dim3(256), 0, s, N, nsplit, cspart,
+    hipLaunchKernelGGL(k_reduce_splits, dim3((N + 63) / 64), dim3(256), 0, s, N, nsplit, cspart,
                        colsum);
 }
 
@@ -477,4 +500,113 @@ void gmpc_launch_polyak(long count, const float* prev, const float* cur, double 
                         hipStream_t s) {
   hipLaunchKernelGGL(k_polyak, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, count, prev, cur,
                      (float)f, (float)(1.0 - f), out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight-gradient GEMM on the matrix cores: C[M][N] = sum_r A[r][:M]^T B[r][:N] with both operands
+// read straight from global memory in their natural row-major layout (the MFMA A operand of k-step
+// r is row r of A, the B operand row r of B: both coalesced).  One wavefront owns a 32 x 32*NTW
+// strip of C over one chunk of rows; partial strips are summed in chunk order (deterministic).
+// Requires N % (32*NTW) == 0 and B padded with >= 8 zero rows; A is clamped (it may be a caller's
+// buffer).  v_mfma_f32_32x32x2_f32 = k-ordered exact fp32 fmaf chain.
+// ---------------------------------------------------------------------------------------------
+template <int NTW>
+__global__ __launch_bounds__(GMPC_THREADS) void k_wgrad_mfma(int rows, int M, int N, const float* A,
+                                                             int lda, const float* Bm, int ldb,
+                                                             int rows_per_chunk, float* Cp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int mstrips = (M + 31) >> 5, ngroups = N / (32 * NTW);
+  const int nchunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+  const int total = mstrips * ngroups * nchunks;
+  const int item = blockIdx.x * (GMPC_THREADS / 64) + wave;
+  if (item >= total) return;
+  const int chunk = item / (mstrips * ngroups);
+  const int rem = item - chunk * mstrips * ngroups;
+  const int mi = rem / ngroups, ng = rem - mi * ngroups;
+  const int r0 = chunk * rows_per_chunk;
+  const int r1 = min(rows, r0 + rows_per_chunk);
+  const int Kp = (r1 - r0 + 1) & ~1;
+  const int acol = mi * 32 + l31;
+  const bool aok = acol < M;
+  const float* ap = A + (aok ? acol : M - 1);
+  auto afn = [&](int k0) -> float {
+    const int r = r0 + k0 + half;
+    const float v = ap[(size_t)min(r, rows - 1) * lda];
+    return (aok && r < r1) ? v : 0.f;
+  };
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
+  const float* bp0 = Bm + (size_t)(r0 + half) * ldb + ng * 32 * NTW + l31;
+  gemm_tile<NTW>(bp0, ldb, Kp, afn, acc);
+  float* cp = Cp + (size_t)chunk * M * N;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int col = ng * 32 * NTW + nt * 32 + l31;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int row = mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+      if (row < M) cp[(size_t)row * N + col] = acc[nt][rg];
+    }
+  }
+}
+
+// column sums of the first cs_rows rows of B: partial[chunk][j]
+__global__ __launch_bounds__(GMPC_THREADS) void k_colsum(int cs_rows, int N, const float* Bm, int ldb,
+                                                         int rows_per_chunk, float* part) {
+  const int chunk = blockIdx.x;
+  const int r0 = chunk * rows_per_chunk, r1 = min(cs_rows, r0 + rows_per_chunk);
+  for (int j = threadIdx.x; j < N; j += blockDim.x) {
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += Bm[(size_t)(r + u) * ldb + j];
+    }
+    for (; r < r1; ++r) a[0] += Bm[(size_t)r * ldb + j];
+    part[(size_t)chunk * N + j] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  }
+}
+
+// MFMA path of gmpc_launch_wgrad; returns false when the shape does not qualify.
+bool gmpc_launch_wgrad_mfma(int rows, int M, int N, const float* A, int lda, const float* Bm, int ldb,
+                            float* C, float* colsum, int cs_rows, float* part, long part_floats,
+                            hipStream_t s) {
+  if (N % 32 != 0 || rows < 64) return false;
+  const int nt_all = N / 32;
+  const int ntw = (nt_all % 8 == 0) ? 8 : (nt_all % 4 == 0) ? 4 : (nt_all % 2 == 0) ? 2 : 1;
+  const int mstrips = (M + 31) / 32, ngroups = nt_all / ntw;
+  int nchunks = 1024 / (mstrips * ngroups);
+  if (nchunks < 1) nchunks = 1;
+  int rpc = (rows + nchunks - 1) / nchunks;
+  if (rpc < 64) rpc = 64;
+  rpc = (rpc + 1) & ~1;
+  nchunks = (rows + rpc - 1) / rpc;
+  while ((long)nchunks * M * N > part_floats && rpc < rows) {
+    rpc *= 2;
+    nchunks = (rows + rpc - 1) / rpc;
+  }
+  if ((long)nchunks * M * N > part_floats) return false;
+  const int total = mstrips * ngroups * nchunks;
+  const dim3 grid((total + 3) / 4), blk(GMPC_THREADS);
+  switch (ntw) {
+    case 8: hipLaunchKernelGGL(k_wgrad_mfma<8>, grid, blk, 0, s, rows, M, N, A, lda, Bm, ldb, rpc, part); break;
+    case 4: hipLaunchKernelGGL(k_wgrad_mfma<4>, grid, blk, 0, s, rows, M, N, A, lda, Bm, ldb, rpc, part); break;
+    case 2: hipLaunchKernelGGL(k_wgrad_mfma<2>, grid, blk, 0, s, rows, M, N, A, lda, Bm, ldb, rpc, part); break;
+    default: hipLaunchKernelGGL(k_wgrad_mfma<1>, grid, blk, 0, s, rows, M, N, A, lda, Bm, ldb, rpc, part); break;
+  }
+  hipLaunchKernelGGL(k_reduce_splits, dim3((M * N + 63) / 64), dim3(256), 0, s, M * N, nchunks, part, C);
+  if (colsum) {
+    int cchunks = (cs_rows + 63) / 64;
+    if (cchunks > 2048) cchunks = 2048;
+    if (cchunks < 1) cchunks = 1;
+    const int crpc = (cs_rows + cchunks - 1) / cchunks;
+    cchunks = (cs_rows + crpc - 1) / crpc;
+    hipLaunchKernelGGL(k_colsum, dim3(cchunks), dim3(GMPC_THREADS), 0, s, cs_rows, N, Bm, ldb, crpc, part);
+    hipLaunchKernelGGL(k_reduce_splits, dim3((N + 63) / 64), dim3(256), 0, s, N, cchunks, part, colsum);
+  }
+  return true;
 }

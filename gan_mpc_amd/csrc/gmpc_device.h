@@ -171,3 +171,62 @@ struct LinPad {
   const float* WLP;                     // [dims[Lh]+2][n]            rows >= dims[Lh] are zero
   const float* WTP[GMPC_MAX_LAYERS];    // l>=1: [dims[l+1]+2][32*NT]; l==0: [dims[1]+2][32*NTF]
 };
+
+// ---- fp32 matrix-core building block -----------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// One GEMM of the chain for one 32-row tile: acc[nt] += A[32 x Kp] * B[Kp x 32*NTT].
+// bp0 points at this lane's element of B row `half` (row stride NP floats, any address space);
+// afn(k0) returns this lane's A element of k-step k0 (k = k0 + half).  B/A of k-step k0+4 are
+// requested before the MFMAs of k-step k0 issue (three register sets, no copies), so two k-steps
+// of matrix work (2*NTT*64 cycles) cover the load latency even at one wave per SIMD.
+// Reads run up to 3 k-steps past Kp: the padded operands provide those rows/columns.
+template <int NTT, typename AF>
+__device__ __forceinline__ void gemm_tile(const float* __restrict__ bp0, int NP, int Kp, AF afn,
+                                          f32x16 (&acc)[NTT]) {
+  float b0[NTT], b1[NTT], b2[NTT];
+  float a0, a1, a2;
+  const float* bp = bp0;
+#pragma unroll
+  for (int nt = 0; nt < NTT; ++nt) b0[nt] = bp[nt * 32];
+  a0 = afn(0);
+  bp += 2 * NP;
+#pragma unroll
+  for (int nt = 0; nt < NTT; ++nt) b1[nt] = bp[nt * 32];
+  a1 = afn(2);
+  int k0 = 0;
+  for (; k0 + 6 <= Kp; k0 += 6) {
+    bp += 2 * NP;
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) b2[nt] = bp[nt * 32];
+    a2 = afn(k0 + 4);
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
+    bp += 2 * NP;
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) b0[nt] = bp[nt * 32];
+    a0 = afn(k0 + 6);
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[nt], acc[nt], 0, 0, 0);
+    bp += 2 * NP;
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) b1[nt] = bp[nt * 32];
+    a1 = afn(k0 + 8);
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[nt], acc[nt], 0, 0, 0);
+  }
+  if (k0 < Kp) {
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt)
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
+    if (k0 + 2 < Kp) {
+#pragma unroll
+      for (int nt = 0; nt < NTT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[nt], acc[nt], 0, 0, 0);
+    }
+  }
+}
+
