@@ -41,21 +41,28 @@ template <int R4>
 __device__ __forceinline__ void dense_rows(const float* __restrict__ W, int K, int N, int j,
                                            const float4* act, float4 (&acc)[R4]) {
   if (j >= N) return;
+  // UNR weight loads are issued before the FMAs that use them: the loop is bound by the L2 latency
+  // of the weight stream, so the number of loads in flight per thread is what matters.
+  constexpr int UNR = R4 <= 2 ? 16 : 8;
   const float* wp = W + j;
   int k = 0;
+  for (; k + UNR <= K; k += UNR) {
+    float w[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) w[u] = wp[(size_t)(k + u) * N];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int q = 0; q < R4; ++q) fma4(acc[q], w[u], act[(k + u) * R4 + q]);
+  }
   for (; k + 4 <= K; k += 4) {
-    const float w0 = wp[(size_t)(k + 0) * N];
-    const float w1 = wp[(size_t)(k + 1) * N];
-    const float w2 = wp[(size_t)(k + 2) * N];
-    const float w3 = wp[(size_t)(k + 3) * N];
+    float w[4];
 #pragma unroll
-    for (int q = 0; q < R4; ++q) fma4(acc[q], w0, act[(k + 0) * R4 + q]);
+    for (int u = 0; u < 4; ++u) w[u] = wp[(size_t)(k + u) * N];
 #pragma unroll
-    for (int q = 0; q < R4; ++q) fma4(acc[q], w1, act[(k + 1) * R4 + q]);
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int q = 0; q < R4; ++q) fma4(acc[q], w2, act[(k + 2) * R4 + q]);
-#pragma unroll
-    for (int q = 0; q < R4; ++q) fma4(acc[q], w3, act[(k + 3) * R4 + q]);
+      for (int q = 0; q < R4; ++q) fma4(acc[q], w[u], act[(k + u) * R4 + q]);
   }
   for (; k < K; ++k) {
     const float w = wp[(size_t)k * N];
@@ -82,7 +89,17 @@ __device__ __forceinline__ void dense_small(const float* __restrict__ W, int K, 
     for (int q = 0; q < R4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int k0 = seg * KS;
     const int k1 = min(K, k0 + KS);
-    for (int k = k0; k < k1; ++k) {
+    int k = k0;
+    for (; k + 8 <= k1; k += 8) {   // 8 weight loads in flight per thread
+      float w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = W[(size_t)(k + u) * N + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int q = 0; q < R4; ++q) fma4(acc[q], w[u], act[(k + u) * R4 + q]);
+    }
+    for (; k < k1; ++k) {
       const float w = W[(size_t)k * N + j];
 #pragma unroll
       for (int q = 0; q < R4; ++q) fma4(acc[q], w, act[k * R4 + q]);
