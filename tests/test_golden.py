@@ -1,0 +1,77 @@
+"""Committed fixtures (tests/golden/build_oracle_small.npz, produced by make_golden.py from the
+build oracle in float64 -- NOT reference output).  CPU: the oracle still
+reproduces them.  GPU: the HIP path matches them."""
+
+import os
+
+import numpy as np
+import pytest
+
+import gan_mpc_oracle as orc
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "build_oracle_small.npz"))
+
+
+def _layers(flat, dims):
+    out, off = [], 0
+    for a, b in zip(dims[:-1], dims[1:]):
+        W = flat[off:off + a * b].reshape(a, b); off += a * b
+        bias = flat[off:off + b]; off += b
+        out.append((W, bias))
+    assert off == flat.size
+    return out
+
+
+def _problem():
+    n, F = int(G["n"]), 64
+    cf = G["critic_flat"]
+    cr = dict(Wx=cf[:n * 4 * F].reshape(n, 4 * F), Wh=cf[n * 4 * F:(n + F) * 4 * F].reshape(F, 4 * F),
+              b=cf[(n + F) * 4 * F:(n + F) * 4 * F + 4 * F],
+              head=_layers(cf[(n + F) * 4 * F + 4 * F:], list(G["head_dims"])))
+    return dict(dyn=_layers(G["dyn_flat"], list(G["dyn_dims"])),
+                cmlp=_layers(G["cost_flat"], list(G["cost_dims"])), mpc_w=G["mpc_w"], critic=cr)
+
+
+def test_oracle_reproduces_golden():
+    p = _problem()
+    X = orc.rollout(p["dyn"], G["U"], G["x0"])
+    np.testing.assert_allclose(X, G["X"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(orc.evaluate(p["cmlp"], p["mpc_w"], G["goal"], X, G["U"]), G["costs"],
+                               rtol=1e-12)
+    lqr = orc.get_lqr_params(p["dyn"], p["cmlp"], p["mpc_w"], G["goal"], X, G["U"])
+    K, k, _, _ = orc.tvlqr(*lqr)
+    np.testing.assert_allclose(K, G["K"], rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(k, G["k"], rtol=1e-9, atol=1e-11)
+    sol = orc.ilqr(p["dyn"], p["cmlp"], p["mpc_w"], G["goal"], G["x0"], G["U"])
+    np.testing.assert_array_equal(sol[6], G["ilqr_iters"])
+    np.testing.assert_allclose(sol[2], G["ilqr_obj"], rtol=1e-9)
+    loss, _ = orc.critic_loss_and_grad(p["critic"], G["true_seq"], G["label"])
+    np.testing.assert_allclose(loss, G["critic_loss"], rtol=1e-12)
+    # the golden iLQR really is a descent: every trajectory improved and stopped
+    obj0 = G["costs"].sum(1)
+    assert (G["ilqr_obj"] < obj0).all() and (G["ilqr_iters"] >= 1).all()
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden():
+    import gpu_util as gu
+    from gan_mpc_amd.engine import Engine
+    n, m, T, B = int(G["n"]), int(G["m"]), int(G["T"]), int(G["B"])
+    eng = Engine(n, m, T, list(G["dyn_dims"]), list(G["cost_dims"]), max_batch=B, lstm_features=64,
+                 head_dims=list(G["head_dims"]))
+    d = eng.to_dev
+    eng.set_params(d(G["mpc_w"]), d(G["dyn_flat"]), d(G["cost_flat"]))
+    X, costs = eng.rollout_cost(d(G["x0"]), d(G["U"]), d(G["goal"]))
+    assert gu.rel_err(X.cpu().numpy(), G["X"]) < 1e-5
+    assert gu.rel_err(costs.cpu().numpy(), G["costs"]) < 1e-5
+    out = eng.lqr_backward(X, d(G["U"]), d(G["goal"]), after_rollout=True)
+    for key in ("AB", "K", "k", "grad", "adjoints"):
+        assert gu.rel_err(out[key].cpu().numpy(), G[key]) < 2e-5, key
+    sol = eng.ilqr_solve(d(G["x0"]), d(G["U"]), d(G["goal"]))
+    # converged optimum: objective value within 1e-4 of the golden fp64 run
+    assert gu.rel_err(sol["obj"].cpu().numpy(), G["ilqr_obj"]) < 1e-4
+    ls, gs = eng.critic_loss_grad(d(G["true_seq"]), d(G["label"]), d(G["critic_flat"]))
+    assert abs(float(ls) / B - float(G["critic_loss"])) < 1e-5 * abs(float(G["critic_loss"]))
+    assert gu.rel_err(gs.cpu().numpy() / B, G["critic_grad"]) < 1e-5
+    score, _ = eng.critic_score_vjp(d(G["true_seq"]), d(G["critic_flat"]), want_dx=False)
+    assert gu.rel_err(score.cpu().numpy(), G["critic_score"]) < 1e-5
