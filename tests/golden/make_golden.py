@@ -33,6 +33,21 @@ def main():
     K, k, P, p = orc.tvlqr(*lqr)
     grad, adj = orc.adjoint(lqr[5], lqr[6], lqr[1], lqr[3])
     sol = orc.ilqr(pb["dyn"], pb["cmlp"], pb["mpc_w"], pb["goal"], pb["x0"], pb["U"])
+    # the oracle's own fp32 error on the same quantities (chained / ill-conditioned ones cannot be
+    # asked to beat fp32): stored so the GPU test can apply the "no worse than 4x" rule offline
+    p32 = orc.cast_problem(pb, np.float32)
+    X32 = orc.rollout(p32["dyn"], p32["U"], p32["x0"])
+    lqr32 = orc.get_lqr_params(p32["dyn"], p32["cmlp"], p32["mpc_w"], p32["goal"], X32, p32["U"])
+    K32, k32, _, _ = orc.tvlqr(*lqr32)
+    g32, a32 = orc.adjoint(lqr32[5], lqr32[6], lqr32[1], lqr32[3])
+
+    def rel(a, ref):
+        return float(np.abs(a - ref).max() / np.abs(ref).max())
+
+    f32_err = dict(
+        AB=rel(np.concatenate([lqr32[5][:, :T], lqr32[6][:, :T]], -1),
+               np.concatenate([lqr[5][:, :T], lqr[6][:, :T]], -1)),
+        K=rel(K32, K), k=rel(k32, k), grad=rel(g32, grad), adjoints=rel(a32, adj))
     label = np.array([1.0, -1.0, 1.0, -1.0, 1.0])
     closs, cgrad = orc.critic_loss_and_grad(pb["critic"], pb["true_seq"], label)
     score = orc.critic_forward(pb["critic"], pb["true_seq"])
@@ -47,6 +62,7 @@ def main():
         grad=grad, adjoints=adj,
         ilqr_X=sol[0], ilqr_U=sol[1], ilqr_obj=sol[2], ilqr_iters=sol[6],
         critic_loss=closs, critic_score=score,
+        **{f"f32err_{k_}": v_ for k_, v_ in f32_err.items()},
         critic_grad=np.concatenate([cgrad["Wx"].ravel(), cgrad["Wh"].ravel(), cgrad["b"].ravel()]
                                    + [t.ravel() for Wb in cgrad["head"] for t in Wb]),
     )

@@ -66,7 +66,10 @@ def test_hip_matches_golden():
     assert gu.rel_err(costs.cpu().numpy(), G["costs"]) < 1e-5
     out = eng.lqr_backward(X, d(G["U"]), d(G["goal"]), after_rollout=True)
     for key in ("AB", "K", "k", "grad", "adjoints"):
-        assert gu.rel_err(out[key].cpu().numpy(), G[key]) < 2e-5, key
+        # 1e-5, or 4x the build oracle's own fp32 error stored with the fixture (the Riccati gains
+        # of this problem are ill-conditioned: R has an eigenvalue alpha^2/|u|^3)
+        tol = max(1e-5, 4.0 * float(G["f32err_" + key]))
+        assert gu.rel_err(out[key].cpu().numpy(), G[key]) < tol, (key, tol)
     sol = eng.ilqr_solve(d(G["x0"]), d(G["U"]), d(G["goal"]))
     # converged optimum: objective value within 1e-4 of the golden fp64 run
     assert gu.rel_err(sol["obj"].cpu().numpy(), G["ilqr_obj"]) < 1e-4
