@@ -41,7 +41,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Lh = dyn.L - 1;
   const int nm = n + m;
-  const long Rtot = (long)B * T * n;
+  const int Rtot = B * T * n;
   const size_t wave_bytes =
       (size_t)(32 * SK + 8) * sizeof(float) + (size_t)Lh * nsmax * GMPC_MW * sizeof(uint32_t);
   float* G = reinterpret_cast<float*>(smem + wave * wave_bytes);
@@ -61,11 +61,12 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
 
   for (int tile = blockIdx.x * (GMPC_THREADS / 64) + wave; tile < ntiles;
        tile += gridDim.x * (GMPC_THREADS / 64)) {
-    const long r0 = (long)tile * 32;
-    const int s_lo = (int)(r0 / n);
-    long rlast = r0 + 31;
+    const int r0 = tile * 32;                 // B*T*n < 2^31 (checked by the launcher)
+    const int s_lo = r0 / n;
+    const int rem0 = r0 - s_lo * n;           // output coordinate of the tile's first row
+    int rlast = r0 + 31;
     if (rlast >= Rtot) rlast = Rtot - 1;
-    const int s_hi = (int)(rlast / n);
+    const int s_hi = rlast / n;
     const int ns = s_hi - s_lo + 1;
     if (active != nullptr) {
       bool any = false;
@@ -80,23 +81,17 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    // this lane's A-operand row and its sample / output coordinate
-    long ra = r0 + l31;
-    if (ra >= Rtot) ra = Rtot - 1;
-    const int sa = (int)(ra / n) - s_lo;
-    const int ia = (int)(ra - (long)(sa + s_lo) * n);
-    // sample index of each accumulator row of this lane: row = (reg&3) + 8*(reg>>2) + 4*half
-    int sreg[16];
-#pragma unroll
-    for (int rg = 0; rg < 16; ++rg) {
-      long rr = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
-      if (rr >= Rtot) rr = Rtot - 1;
-      sreg[rg] = (int)(rr / n) - s_lo;
-    }
+    // this lane's A-operand row (row l31 of the tile): its sample and output coordinate
+    int sa = (rem0 + l31) / n;
+    if (sa > ns - 1) sa = ns - 1;              // rows past the end of the batch: clamp (discarded)
+    int ia = rem0 + l31 - sa * n;
+    if (ia > n - 1) ia = n - 1;
     // A element of the seed tile: W_L[k][i_row] * relu bit(layer Lh-1, sample of row, k)
-    const uint32_t* mrow = mk + ((Lh - 1) * nsmax + sa) * GMPC_MW;
     const float* wl_g = lp.WLP + (size_t)half * n + ia;
     const float* wl_l = wl_s + half * n + ia;
+    const float* aptr = G + l31 * SK + half;
+    // relu bits of this lane's row for the layer whose output is being consumed (set per GEMM)
+    const uint32_t* mrow = mk + ((Lh - 1) * nsmax + sa) * GMPC_MW;
     auto a_seed_g = [&](int k0) -> float {
       const int k = k0 + half;
       const uint32_t w = mrow[(k >> 5) & (GMPC_MW - 1)];
@@ -109,8 +104,14 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
       const float v = wl_l[k0 * n];
       return ((w >> (k & 31)) & 1u) ? v : 0.f;
     };
-    const float* aptr = G + l31 * SK + half;
-    auto a_slab = [&](int k0) -> float { return aptr[k0]; };
+    // A element from the slab: the unmasked accumulator of the previous GEMM times the relu bit of
+    // its column -- the mask is applied here, in the shadow of the MFMAs, not in the epilogue
+    auto a_slab = [&](int k0) -> float {
+      const int k = k0 + half;
+      const uint32_t w = mrow[(k >> 5) & (GMPC_MW - 1)];
+      const float v = aptr[k0];
+      return ((w >> (k & 31)) & 1u) ? v : 0.f;
+    };
 
     f32x16 acc[NT];
     // ================= hidden GEMMs: l = Lh-1 (seeded from W_L) ... 1 =================
@@ -122,24 +123,24 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
       const float* __restrict__ bp0 = lp.WTP[l] + (size_t)half * NP + l31;
+      // the A operand of this GEMM carries the relu bits of hidden layer l (its k index)
+      mrow = mk + (l * nsmax + sa) * GMPC_MW;
       if (l == Lh - 1) {
         if (stage_wl) gemm_tile<NT>(bp0, NP, Kp, a_seed_l, acc);
         else gemm_tile<NT>(bp0, NP, Kp, a_seed_g, acc);
       } else {
         gemm_tile<NT>(bp0, NP, Kp, a_slab, acc);
       }
-      // ---- epilogue: mask with the relu bits of hidden layer l-1, write the next A operand.
-      // Columns >= dims[l] come out as exact zeros (zero-padded B, zero mask bits), which also
-      // provides the zero pad columns the next GEMM's read-ahead and an odd K need.
+      // ---- epilogue: the raw accumulator becomes the next A operand (masked when it is read).
+      // Columns >= dims[l] are exact zeros (zero-padded B), which provides the zero pad columns the
+      // next GEMM's read-ahead and an odd K need.
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
           const int row = (rg & 3) + 8 * (rg >> 2) + 4 * half;
-          const uint32_t w = mk[((l - 1) * nsmax + sreg[rg]) * GMPC_MW + nt];
-          const float v = ((w >> l31) & 1u) ? acc[nt][rg] : 0.f;
-          G[row * SK + nt * 32 + l31] = v;
+          G[row * SK + nt * 32 + l31] = acc[nt][rg];
         }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
         for (int rg = 0; rg < 16; ++rg) acc0[nt][rg] = 0.f;
       const float* bp_g = lp.WTP[0] + (size_t)half * NPF + l31;
       const float* bp_l = w1_s + half * NPF + l31;
+      mrow = mk + (0 * nsmax + sa) * GMPC_MW;   // relu bits of hidden layer 0 (k index of this GEMM)
       if (Lh == 1) {
         // single hidden layer: the seed tile feeds the input GEMM directly
         if (stage_w1) {
@@ -175,9 +177,10 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
         if (c < nm) {
 #pragma unroll
           for (int rg = 0; rg < 16; ++rg) {
-            const long rr = r0 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+            const int o = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+            const int rr = r0 + o;
             if (rr < Rtot) {
-              const int irow = (int)(rr - (long)(sreg[rg] + s_lo) * n);
+              const int irow = (rem0 + o) % n;   // output coordinate of this accumulator row
               AB[(size_t)rr * nm + c] = acc0[nt][rg] + (c == irow ? 1.0f : 0.0f);
             }
           }
@@ -229,6 +232,7 @@ template <int NT, int NTF>
 static int launch_mfma(int B, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
                        const uint32_t* masks, const int* active, float* AB, hipStream_t s) {
   const long Rtot = (long)B * T * n;
+  if (Rtot >= (1L << 31) - 64) return -1;
   const int ntiles = (int)((Rtot + 31) / 32);
   const int nsmax = 32 / n + 2;
   const int Lh = dyn.L - 1;
