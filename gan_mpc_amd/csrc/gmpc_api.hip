@@ -248,7 +248,7 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
   A_(Hout, B * T * m);
   A_(dX, B * (T + 1) * n);
   A_(gmpc, B * 3);
-  A_(cact, 2 * B * c->cstride);
+  A_(cact, (2 * B + 8) * c->cstride);
   A_(cdel, (2 * B + 8) * c->cstride);
   A_(bl_loss, B);
   // critic
@@ -269,7 +269,7 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
     A_(hp, Bc * T1 * F);
     A_(hT, Bc * F);
     A_(dz, (Bc * T1 + 8) * 4 * F);
-    A_(hacts, Bc * c->hstride);
+    A_(hacts, (Bc + 8) * c->hstride);
     A_(hdels, (Bc + 8) * c->hstride);
     A_(dhT, Bc * F);
     A_(cscore, Bc);
@@ -288,9 +288,11 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
 #undef A_
   // B operands of the MFMA weight-gradient GEMM are read a few rows past the end: keep them finite
   if (!rc && c->cdel) (void)hipMemset(c->cdel, 0, (2 * B + 8) * c->cstride * sizeof(float));
+  if (!rc && c->cact) (void)hipMemset(c->cact, 0, (2 * B + 8) * c->cstride * sizeof(float));
   if (!rc && s.lstm_features > 0) {
     (void)hipMemset(c->dz, 0, ((size_t)2 * B * (T + 1) + 8) * 4 * s.lstm_features * sizeof(float));
     (void)hipMemset(c->hdels, 0, ((size_t)2 * B + 8) * c->hstride * sizeof(float));
+    (void)hipMemset(c->hacts, 0, ((size_t)2 * B + 8) * c->hstride * sizeof(float));
   }
   if (rc) {
     gmpc_destroy(c);

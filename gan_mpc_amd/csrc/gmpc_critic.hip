@@ -14,14 +14,19 @@
 template <int R4>
 __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd, const float* xseq,
                                                            float* gates, float* cs, float* hp,
-                                                           float* hT) {
+                                                           float* hT, int stage_w) {
   constexpr int SB = 4 * R4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* act = reinterpret_cast<float4*>(smem);            // [(n+F)][R4]
   float4* gbuf = act + (cd.n + cd.F) * R4;                  // [4F][R4]
+  float* wlds = reinterpret_cast<float*>(gbuf + 4 * cd.F * R4);   // [(n+F)][4F] when staged
   const int tid = threadIdx.x;
   const int n = cd.n, F = cd.F, T1 = cd.T1, G4 = 4 * F, K = n + F;
   const int s0 = blockIdx.x * SB;
+  // the whole [Wx; Wh] block (83 KB at n = 17) lives in LDS for all T+1 steps: every step then
+  // reads its weights at LDS latency instead of L2 latency
+  if (stage_w)
+    for (int e = tid; e < K * G4; e += blockDim.x) wlds[e] = cd.Wcat[e];
   const int u = tid % F, grp = tid / F;       // cell-update role (F*4 == blockDim)
   constexpr int SPT = SB / 4;                 // sequences per thread in the cell update
   float c[SPT];
@@ -46,7 +51,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd
     float4 acc[R4];
 #pragma unroll
     for (int q = 0; q < R4; ++q) acc[q] = make_float4(bj, bj, bj, bj);
-    dense_rows<R4>(cd.Wcat, K, G4, tid, act, acc);
+    if (stage_w) dense_rows_lds<R4>(wlds, K, G4, tid, act, acc);
+    else dense_rows<R4>(cd.Wcat, K, G4, tid, act, acc);
     if (tid < G4) {
       const bool is_g = (tid >= 2 * F) && (tid < 3 * F);
 #pragma unroll
@@ -208,17 +214,20 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_head(int Bc, CriticDesc cd, in
 template <int R4>
 __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd, const float* gates,
                                                            const float* cs, const float* dhT,
-                                                           float* dz, float* dxseq) {
+                                                           float* dz, float* dxseq, int stage_w) {
   constexpr int SB = 4 * R4;
   constexpr int SPT = SB / 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* dzb = reinterpret_cast<float4*>(smem);            // [4F][R4]
   float4* part = dzb + GMPC_THREADS * R4;                   // dense_small scratch / result
+  float* wlds = reinterpret_cast<float*>(part + GMPC_THREADS * R4);   // [4F][(n+F)] when staged
   const int tid = threadIdx.x;
   const int n = cd.n, F = cd.F, T1 = cd.T1, G4 = 4 * F, K = n + F;
   const int s0 = blockIdx.x * SB;
   const int u = tid % F, grp = tid / F;
   float* dzf = reinterpret_cast<float*>(dzb);
+  if (stage_w)
+    for (int e = tid; e < K * G4; e += blockDim.x) wlds[e] = cd.WcatT[e];
   float dh[SPT], dc[SPT];
 #pragma unroll
   for (int e = 0; e < SPT; ++e) {
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd
     }
     __syncthreads();
     // [dx ; dh_prev][k][sb] = sum_j WcatT[j][k] dz[j][sb]
-    dense_small<R4>(cd.WcatT, G4, K, dzb, part);
+    dense_small<R4>(stage_w ? wlds : cd.WcatT, G4, K, dzb, part);
     const float* pf = reinterpret_cast<const float*>(part);
 #pragma unroll
     for (int e = 0; e < SPT; ++e) dh[e] = pf[(n + u) * SB + grp * SPT + e];
@@ -419,15 +428,26 @@ void gmpc_launch_transpose(int R, int C, const float* in, float* out, hipStream_
   hipLaunchKernelGGL(k_transpose, dim3((cnt + 255) / 256), dim3(256), 0, s, R, C, in, out);
 }
 
-#define GMPC_CR4 2   // 8 sequences per workgroup
+#define GMPC_CR4 1   // 4 sequences per workgroup
 
 void gmpc_launch_lstm_fwd(int Bc, const CriticDesc& cd, const float* xseq, float* gates, float* cs,
                           float* hp, float* hT, hipStream_t s) {
   constexpr int R4 = GMPC_CR4;
   const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
-  const size_t lds = ((size_t)(cd.n + cd.F) + 4 * cd.F) * R4 * sizeof(float4);
+  size_t lds = ((size_t)(cd.n + cd.F) + 4 * cd.F) * R4 * sizeof(float4);
+  const size_t wbytes = (size_t)(cd.n + cd.F) * 4 * cd.F * sizeof(float);
+  // measured on MI355X: staging [Wx;Wh] in LDS does not pay (0.25 -> 0.28 ms): the step is bound by
+  // instruction issue (transcendentals + FMAs at one wave per SIMD), not by the L2 weight stream
+  const int stage_w = 0 * (lds + wbytes <= 150 * 1024);
+  if (stage_w) lds += wbytes;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_fwd<R4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
   hipLaunchKernelGGL(k_lstm_fwd<R4>, dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates, cs,
-                     hp, hT);
+                     hp, hT, stage_w);
 }
 
 void gmpc_launch_head(int Bc, const CriticDesc& cd, int loss_kind, const float* hT,
@@ -445,9 +465,18 @@ void gmpc_launch_lstm_bwd(int Bc, const CriticDesc& cd, const float* gates, cons
                           const float* dhT, float* dz, float* dxseq, hipStream_t s) {
   constexpr int R4 = GMPC_CR4;
   const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
-  const size_t lds = 2 * (size_t)GMPC_THREADS * R4 * sizeof(float4);
+  size_t lds = 2 * (size_t)GMPC_THREADS * R4 * sizeof(float4);
+  const size_t wbytes = (size_t)(cd.n + cd.F) * 4 * cd.F * sizeof(float);
+  const int stage_w = 0 * (lds + wbytes <= 150 * 1024);   // no gain measured (see k_lstm_fwd)
+  if (stage_w) lds += wbytes;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_bwd<R4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
   hipLaunchKernelGGL(k_lstm_bwd<R4>, dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, gates, cs, dhT,
-                     dz, dxseq);
+                     dz, dxseq, stage_w);
 }
 
 // C[M][N] = sum_r A[r][:M]^T B[r][:N]; colsum[N] = sum_{r < cs_rows} B[r][:N] (optional).
@@ -455,6 +484,7 @@ void gmpc_launch_lstm_bwd(int Bc, const CriticDesc& cd, const float* gates, cons
 bool gmpc_launch_wgrad_mfma(int rows, int M, int N, const float* A, int lda, const float* Bm, int ldb,
                             float* C, float* colsum, int cs_rows, float* part, long part_floats,
                             hipStream_t s);
+__global__ void k_colsum(int cs_rows, int N, const float* Bm, int ldb, int rows_per_chunk, float* part);
 
 // part holds part_floats floats (at least max_split*(M*N + N)); mfma_ok: B has >= 8 zero pad rows
 void gmpc_launch_wgrad(int rows, int M, int N, const float* A, int lda, const float* Bm, int ldb,
@@ -463,6 +493,23 @@ void gmpc_launch_wgrad(int rows, int M, int N, const float* A, int lda, const fl
   if (mfma_ok && gmpc_launch_wgrad_mfma(rows, M, N, A, lda, Bm, ldb, C, colsum, cs_rows, part,
                                         part_floats, s))
     return;
+  // narrow N (e.g. the critic head's last layer, N = 1): compute C^T = sum_r B_r^T A_r instead;
+  // C^T (N x M) has the same memory image as C when N == 1, otherwise it is transposed afterwards
+  if (mfma_ok && N == 1 && M % 32 == 0 &&
+      gmpc_launch_wgrad_mfma(rows, 1, M, Bm, ldb, A, lda, C, nullptr, 0, part, part_floats, s)) {
+    if (colsum) {
+      const float* Bc_ = Bm;
+      int cchunks = (cs_rows + 63) / 64;
+      if (cchunks > 2048) cchunks = 2048;
+      const int crpc = (cs_rows + cchunks - 1) / cchunks;
+      cchunks = (cs_rows + crpc - 1) / crpc;
+      hipLaunchKernelGGL(k_colsum, dim3(cchunks), dim3(GMPC_THREADS), 0, s, cs_rows, N, Bc_, ldb, crpc,
+                         part);
+      hipLaunchKernelGGL(k_reduce_splits, dim3((N + 63) / 64), dim3(256), 0, s, N, cchunks, part,
+                         colsum);
+    }
+    return;
+  }
   int nsplit = (rows + 511) / 512;
   if (nsplit > max_split) nsplit = max_split;
   if (nsplit < 1) nsplit = 1;

@@ -71,6 +71,20 @@ __device__ __forceinline__ void dense_rows(const float* __restrict__ W, int K, i
   }
 }
 
+// dense_rows with the weight matrix resident in LDS (bank-conflict free: lanes read consecutive j).
+template <int R4>
+__device__ __forceinline__ void dense_rows_lds(const float* W, int K, int N, int j, const float4* act,
+                                               float4 (&acc)[R4]) {
+  if (j >= N) return;
+  const float* wp = W + j;
+#pragma unroll 4
+  for (int k = 0; k < K; ++k) {
+    const float w = wp[k * N];
+#pragma unroll
+    for (int q = 0; q < R4; ++q) fma4(acc[q], w, act[k * R4 + q]);
+  }
+}
+
 // Same product for a narrow output (N << blockDim): the K range is split over NS = blockDim/N
 // thread groups, partial sums meet in LDS and are added in segment order (deterministic).
 // On return (after the trailing barrier) part[j*R4 + q] holds the sums; `part` needs
