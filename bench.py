@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend: nccl (= RCCL over xGMI, the real thing) or gloo "
+                         "(rehearsal of the multi-rank path on a box with fewer GPUs than ranks)")
     args = ap.parse_args()
 
     import numpy as np
@@ -123,10 +126,14 @@ def main():
                          f"(WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: gan_mpc_amd has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks need {world} GPUs (found {ndev}); use --backend gloo to rehearse")
+    dev_index = local_rank % ndev          # identity on a full node; ranks share GPUs only under gloo
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gan_mpc_oracle as orc  # synthetic-problem generator only (inputs), never in the timed path
@@ -145,7 +152,7 @@ def main():
     cost_dims = [n, *w["cost_hidden"], w["cost_fout"]]
     head_dims = [F, *w["head_hidden"], 1]
     eng = Engine(n, m, T, dyn_dims, cost_dims, max_batch=B, lstm_features=F, head_dims=head_dims,
-                 device=local_rank)
+                 device=dev_index)
     d = eng.to_dev
     # identical (seed 0) parameters on every rank, rank-specific trajectories
     eng.set_params(d(wts["mpc_w"]), d(P.pack_mlp(P.layers_to_tree(wts["dyn"]))),
@@ -200,12 +207,13 @@ def main():
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
     roof = None
     prof = {}
+    nprof = min(args.steps, 10)
     if rank == 0:
         eng.profile_enable(True)
-        nprof = min(args.steps, 10)
-        for k in range(nprof):
-            step(args.warmup + args.steps + k)
-        torch.cuda.synchronize()
+    for k in range(nprof):       # every rank runs these steps: they contain the collective
+        step(args.warmup + args.steps + k)
+    torch.cuda.synchronize()
+    if rank == 0:
         prof = eng.profile_read()
         eng.profile_enable(False)
         dom = max(prof, key=lambda kk: prof[kk][0])
