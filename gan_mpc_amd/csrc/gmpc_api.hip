@@ -320,6 +320,10 @@ extern "C" int gmpc_set_params(gmpc_ctx* c, const float* mpc_w, const float* dyn
   transpose_mlp(c->dyn, s);
   transpose_mlp(c->cost, s);
   gmpc_linpad_prepare(c->dyn, c->sh.n, c->sh.m, c->linpad, c->linpad_floats, &c->lp, s);
+  if (getenv("GMPC_LIN_STAMPS")) {   // diagnostic build of the timing only; never set in production
+    (void)hipMemsetAsync(c->scratch + 768, 0, 64, s);
+    c->lp.dbg = reinterpret_cast<unsigned long long*>(c->scratch + 768);
+  }
   HIP_TRY(hipGetLastError());
   c->params_set = true;
   return 0;
@@ -693,7 +697,7 @@ extern "C" const float* gmpc_debug_buffer(gmpc_ctx* c, int which) {
   switch (which) {
     case 0: return c->Xs; case 1: return c->Us; case 2: return c->Hout; case 3: return c->dX;
     case 4: return c->Bvec; case 5: return c->AB; case 6: return c->Ks; case 7: return c->ks;
-    case 12: return c->Xc; case 13: return c->Uc;
+    case 14: return c->scratch + 768; case 12: return c->Xc; case 13: return c->Uc;
     case 8: return c->alpha; case 9: return c->obj_step; case 10: return c->U_step;
     default: return nullptr;
   }

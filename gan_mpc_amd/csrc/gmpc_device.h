@@ -201,6 +201,7 @@ struct LinPad {
   int NT, NTF;                          // column tiles of the hidden GEMMs / of the input GEMM
   const float* WLP;                     // [dims[Lh]+2][n]            rows >= dims[Lh] are zero
   const float* WTP[GMPC_MAX_LAYERS];    // l>=1: [dims[l+1]+2][32*NT]; l==0: [dims[1]+2][32*NTF]
+  unsigned long long* dbg;              // diagnostic: per-segment cycle sums (null in production)
 };
 
 // ---- fp32 matrix-core building block -----------------------------------------------------------
@@ -226,28 +227,36 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ bp0, int NP,
   for (int nt = 0; nt < NTT; ++nt) b1[nt] = bp[nt * 32];
   a1 = afn(2);
   int k0 = 0;
+  // sched_barrier(0) pins "request k-step k0+4, then run k-step k0": without it hipcc sinks the loads
+  // below the MFMAs and the prefetch distance shrinks to one k-step.
   for (; k0 + 6 <= Kp; k0 += 6) {
     bp += 2 * NP;
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) b2[nt] = bp[nt * 32];
     a2 = afn(k0 + 4);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt)
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0[nt], acc[nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     bp += 2 * NP;
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) b0[nt] = bp[nt * 32];
     a0 = afn(k0 + 6);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt)
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[nt], acc[nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
     bp += 2 * NP;
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt) b1[nt] = bp[nt * 32];
     a1 = afn(k0 + 8);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int nt = 0; nt < NTT; ++nt)
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[nt], acc[nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   if (k0 < Kp) {
 #pragma unroll
@@ -261,3 +270,86 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ bp0, int NP,
   }
 }
 
+// A-operand source for the ring-buffered GEMMs below.  load() only ISSUES the reads of k-step k0 and
+// returns the raw words; fin() turns them into the MFMA operand when the k-step is consumed, two or
+// more k-steps later.  Splitting the two keeps the dependent VALU work (the relu select) away from
+// the read, so no k-step waits for its own LDS round trip.
+struct ARaw { float v; uint32_t w; };
+
+// Same GEMM with B in the lane-interleaved layout Wi[k][32 lanes][8]: the (up to 8) column-tile
+// values one lane needs for a k row are 32 contiguous bytes, fetched by two dwordx4 loads instead of
+// NTT dword loads (measured 81 -> 73 cycles per MFMA at one wave per SIMD).  bp0 points at this
+// lane's float4 pair of row `half`; the row stride is 64 float4.
+template <int NTT, typename AL, typename AFIN>
+__device__ __forceinline__ void gemm_tile_x4(const float4* __restrict__ bp0, int Kp, AL aload, AFIN afin,
+                                             f32x16 (&acc)[NTT]) {
+  static_assert(NTT <= 8, "at most 8 column tiles");
+  float4 b0[2], b1[2], b2[2];
+  ARaw a0, a1, a2;
+  const float4* bp = bp0;
+  auto ld = [&](float4 (&b)[2]) {
+    b[0] = bp[0];
+    if (NTT > 4) b[1] = bp[1];
+  };
+  auto mf = [&](const ARaw& ar, int k0, const float4 (&b)[2]) {
+    const float a = afin(ar, k0);
+#pragma unroll
+    for (int nt = 0; nt < NTT; ++nt) {
+      const float4& q = b[nt >> 2];
+      const float bv = (nt & 3) == 0 ? q.x : (nt & 3) == 1 ? q.y : (nt & 3) == 2 ? q.z : q.w;
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[nt], 0, 0, 0);
+    }
+  };
+  ld(b0); a0 = aload(0); bp += 128;
+  ld(b1); a1 = aload(2);
+  int k0 = 0;
+  for (; k0 + 6 <= Kp; k0 += 6) {
+    // Each third of the body requests the operands of k-step +4 and runs the MFMAs of the current
+    // one.  The sched_group_barrier sequence spreads the non-MFMA instructions (2 vector-memory
+    // reads, 2 LDS reads, the relu select and the pointer bumps) BETWEEN the MFMAs: issued as a block
+    // they do not overlap the matrix pipe at one wave per SIMD (measured 84 vs 64 cycles per MFMA).
+#define GMPC_INTERLEAVE()                                                        \
+    _Pragma("unroll") for (int i_ = 0; i_ < NTT; ++i_) {                          \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  /* 1 MFMA */            \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  /* <=1 VMEM read */     \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  /* <=1 LDS read */      \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  /* <=2 VALU */          \
+      __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);  /* <=2 SALU */          \
+    }
+    bp += 128; ld(b2); a2 = aload(k0 + 4);
+    mf(a0, k0, b0);
+    GMPC_INTERLEAVE()
+    bp += 128; ld(b0); a0 = aload(k0 + 6);
+    mf(a1, k0 + 2, b1);
+    GMPC_INTERLEAVE()
+    bp += 128; ld(b1); a1 = aload(k0 + 8);
+    mf(a2, k0 + 4, b2);
+    GMPC_INTERLEAVE()
+#undef GMPC_INTERLEAVE
+  }
+  if (k0 < Kp) {
+    mf(a0, k0, b0);
+    if (k0 + 2 < Kp) mf(a1, k0 + 2, b1);
+  }
+}
+
+// Single-column-tile GEMM (the input layer: one MFMA per k-step, so operand latency is exposed):
+// six register sets, operands requested five k-steps (320 MFMA cycles) ahead.  Runs whole groups of
+// six k-steps: k-steps past Kp must contribute zero (afin returns 0 there; B rows are zero-padded).
+template <typename AL, typename AFIN, typename BF>
+__device__ __forceinline__ void gemm_tile_1(int Kp, AL aload, AFIN afin, BF bfn, f32x16& acc) {
+  ARaw a[6];
+  float b[6];
+#pragma unroll
+  for (int u = 0; u < 5; ++u) { a[u] = aload(2 * u); b[u] = bfn(2 * u); }
+  for (int k0 = 0; k0 < Kp; k0 += 12) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {
+      a[(u + 5) % 6] = aload(k0 + 2 * (u + 5));
+      b[(u + 5) % 6] = bfn(k0 + 2 * (u + 5));
+      __builtin_amdgcn_sched_barrier(0);   // keep the requests five k-steps ahead of their use
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(afin(a[u], k0 + 2 * u), b[u], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}

@@ -28,7 +28,15 @@ __global__ void k_pad_transpose(int in, int out, const float* W, float* dst, int
   dst[(size_t)o * ldo + i] = W[e];
 }
 
-#define GMPC_LIN_PADROWS 8   // zero rows after the last k row of every padded operand
+#define GMPC_LIN_PADROWS 24   // zero rows after the last k row of every padded operand
+
+// hidden layers: dst[o][l31][nt] = W[i = nt*32 + l31][o]  (lane-interleaved, 8 slots per lane)
+__global__ void k_pad_transpose_x4(int in, int out, const float* W, float* dst) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= in * out) return;
+  const int i = e / out, o = e - i * out;
+  dst[(size_t)o * 256 + (i & 31) * 8 + (i >> 5)] = W[e];
+}
 
 template <int NT, int NTF>
 __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
@@ -58,6 +66,12 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
     for (int e = threadIdx.x; e < w1_floats; e += blockDim.x) w1_s[e] = lp.WTP[0][e];
   __syncthreads();   // the only workgroup barrier: after it the waves are independent
   const int half = lane >> 5, l31 = lane & 31;
+  // diagnostic stamps (GMPC_LIN_STAMPS=1): cycles per segment summed over tiles; slots: 0 staging +
+  // prologue, 1 hidden GEMMs, 2 hidden epilogues, 3 input GEMM, 4 output stores
+  unsigned long long st[5] = {0, 0, 0, 0, 0}, tprev = 0;
+  const bool stamps = lp.dbg != nullptr;
+#define GMPC_STAMP(i) if (stamps) { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - tprev; tprev = t_; }
+  if (stamps) tprev = __builtin_readcyclecounter();
 
   for (int tile = blockIdx.x * (GMPC_THREADS / 64) + wave; tile < ntiles;
        tile += gridDim.x * (GMPC_THREADS / 64)) {
@@ -92,27 +106,30 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
     const float* aptr = G + l31 * SK + half;
     // relu bits of this lane's row for the layer whose output is being consumed (set per GEMM)
     const uint32_t* mrow = mk + ((Lh - 1) * nsmax + sa) * GMPC_MW;
-    auto a_seed_g = [&](int k0) -> float {
+    // raw A loads (value + relu word of its k column) and the finishing select
+    auto l_seed_g = [&](int k0) -> ARaw {
       const int k = k0 + half;
-      const uint32_t w = mrow[(k >> 5) & (GMPC_MW - 1)];
-      const float v = wl_g[(size_t)k0 * n];
-      return ((w >> (k & 31)) & 1u) ? v : 0.f;
+      return ARaw{wl_g[(size_t)k0 * n], mrow[(k >> 5) & (GMPC_MW - 1)]};
     };
-    auto a_seed_l = [&](int k0) -> float {
+    auto l_seed_l = [&](int k0) -> ARaw {
       const int k = k0 + half;
-      const uint32_t w = mrow[(k >> 5) & (GMPC_MW - 1)];
-      const float v = wl_l[k0 * n];
-      return ((w >> (k & 31)) & 1u) ? v : 0.f;
+      return ARaw{wl_l[k0 * n], mrow[(k >> 5) & (GMPC_MW - 1)]};
     };
-    // A element from the slab: the unmasked accumulator of the previous GEMM times the relu bit of
-    // its column -- the mask is applied here, in the shadow of the MFMAs, not in the epilogue
-    auto a_slab = [&](int k0) -> float {
+    // from the slab: the unmasked accumulator of the previous GEMM; its relu bit is applied when the
+    // operand is consumed -- in the shadow of the MFMAs, not in the epilogue
+    auto l_slab = [&](int k0) -> ARaw {
       const int k = k0 + half;
-      const uint32_t w = mrow[(k >> 5) & (GMPC_MW - 1)];
-      const float v = aptr[k0];
-      return ((w >> (k & 31)) & 1u) ? v : 0.f;
+      return ARaw{aptr[k0], mrow[(k >> 5) & (GMPC_MW - 1)]};
     };
+    auto a_fin = [&](const ARaw& r, int k0) -> float {
+      return ((r.w >> ((k0 + half) & 31)) & 1u) ? r.v : 0.f;
+    };
+    // plain float sources for the generic gemm_tile (multi-tile input GEMMs, single hidden layer)
+    auto a_seed_g = [&](int k0) -> float { return a_fin(l_seed_g(k0), k0); };
+    auto a_seed_l = [&](int k0) -> float { return a_fin(l_seed_l(k0), k0); };
+    auto a_slab = [&](int k0) -> float { return a_fin(l_slab(k0), k0); };
 
+    GMPC_STAMP(0)
     f32x16 acc[NT];
     // ================= hidden GEMMs: l = Lh-1 (seeded from W_L) ... 1 =================
     for (int l = Lh - 1; l >= 1; --l) {
@@ -122,15 +139,18 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
-      const float* __restrict__ bp0 = lp.WTP[l] + (size_t)half * NP + l31;
+      // lane-interleaved padded W_l^T: this lane's 8 column-tile slots of row `half`
+      const float4* __restrict__ bp0 =
+          reinterpret_cast<const float4*>(lp.WTP[l]) + half * 64 + l31 * 2;
       // the A operand of this GEMM carries the relu bits of hidden layer l (its k index)
       mrow = mk + (l * nsmax + sa) * GMPC_MW;
       if (l == Lh - 1) {
-        if (stage_wl) gemm_tile<NT>(bp0, NP, Kp, a_seed_l, acc);
-        else gemm_tile<NT>(bp0, NP, Kp, a_seed_g, acc);
+        if (stage_wl) gemm_tile_x4<NT>(bp0, Kp, l_seed_l, a_fin, acc);
+        else gemm_tile_x4<NT>(bp0, Kp, l_seed_g, a_fin, acc);
       } else {
-        gemm_tile<NT>(bp0, NP, Kp, a_slab, acc);
+        gemm_tile_x4<NT>(bp0, Kp, l_slab, a_fin, acc);
       }
+      GMPC_STAMP(1)
       // ---- epilogue: the raw accumulator becomes the next A operand (masked when it is read).
       // Columns >= dims[l] are exact zeros (zero-padded B), which provides the zero pad columns the
       // next GEMM's read-ahead and an odd K need.
@@ -145,6 +165,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_wave_barrier();
+      GMPC_STAMP(2)
     }
     // ================= input GEMM (l = 0): N = n + m columns, NTF tiles =================
     {
@@ -167,10 +188,22 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
           if (stage_wl) gemm_tile<NTF>(bp_g, NPF, Kp, a_seed_l, acc0);
           else gemm_tile<NTF>(bp_g, NPF, Kp, a_seed_g, acc0);
         }
+      } else if (NTF == 1) {
+        // one MFMA per k-step: deep operand ring; k-steps past Kp multiply zeros (A clamped to 0,
+        // B rows zero-padded)
+        auto fin_deep = [&](const ARaw& r, int k0) -> float { return k0 < Kp ? a_fin(r, k0) : 0.f; };
+        if (stage_w1) {
+          auto b_l = [&](int k0) -> float { return bp_l[k0 * NPF]; };
+          gemm_tile_1(Kp, l_slab, fin_deep, b_l, acc0[0]);
+        } else {
+          auto b_g = [&](int k0) -> float { return bp_g[(size_t)k0 * NPF]; };
+          gemm_tile_1(Kp, l_slab, fin_deep, b_g, acc0[0]);
+        }
       } else {
         if (stage_w1) gemm_tile<NTF>(bp_l, NPF, Kp, a_slab, acc0);
         else gemm_tile<NTF>(bp_g, NPF, Kp, a_slab, acc0);
       }
+      GMPC_STAMP(3)
 #pragma unroll
       for (int nt = 0; nt < NTF; ++nt) {
         const int c = nt * 32 + l31;
@@ -188,7 +221,11 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
       }
     }
     __builtin_amdgcn_wave_barrier();
+    GMPC_STAMP(4)
   }
+  if (stamps && lane == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&lp.dbg[i], st[i]);
+#undef GMPC_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -199,7 +236,7 @@ size_t gmpc_linpad_floats(const gmpc_shape* sh) {
   const int NT = (wmax + 31) / 32, NTF = (sh->n + sh->m + 31) / 32;
   size_t f = (size_t)(sh->dyn_dims[Lh] + GMPC_LIN_PADROWS) * sh->n;
   f += (size_t)(sh->dyn_dims[1] + GMPC_LIN_PADROWS) * 32 * NTF;
-  for (int l = 1; l < Lh; ++l) f += (size_t)(sh->dyn_dims[l + 1] + GMPC_LIN_PADROWS) * 32 * NT;
+  for (int l = 1; l < Lh; ++l) f += (size_t)(sh->dyn_dims[l + 1] + GMPC_LIN_PADROWS) * 256;
   return f + 64;
 }
 
@@ -211,6 +248,7 @@ void gmpc_linpad_prepare(const MlpDesc& dyn, int n, int m, float* pad, size_t pa
   for (int l = 1; l < dyn.L; ++l) wmax = dyn.dims[l] > wmax ? dyn.dims[l] : wmax;
   out->NT = (wmax + 31) / 32;
   out->NTF = (n + m + 31) / 32;
+  out->dbg = nullptr;
   (void)hipMemsetAsync(pad, 0, pad_floats * sizeof(float), s);
   float* p = pad;
   // W_L: (dims[Lh] x n) row-major already is [k][i]; copy, padded rows stay zero
@@ -219,11 +257,15 @@ void gmpc_linpad_prepare(const MlpDesc& dyn, int n, int m, float* pad, size_t pa
   p += (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;
   for (int l = 0; l < Lh; ++l) {
     const int in = dyn.dims[l], outd = dyn.dims[l + 1];
-    const int ldo = 32 * (l == 0 ? out->NTF : out->NT);
+    const int ldo = (l == 0) ? 32 * out->NTF : 256;
     out->WTP[l] = p;
     const int cnt = in * outd;
-    hipLaunchKernelGGL(k_pad_transpose, dim3((cnt + 255) / 256), dim3(256), 0, s, in, outd, dyn.W[l],
-                       p, ldo);
+    if (l == 0)
+      hipLaunchKernelGGL(k_pad_transpose, dim3((cnt + 255) / 256), dim3(256), 0, s, in, outd, dyn.W[l],
+                         p, ldo);
+    else
+      hipLaunchKernelGGL(k_pad_transpose_x4, dim3((cnt + 255) / 256), dim3(256), 0, s, in, outd,
+                         dyn.W[l], p);
     p += (size_t)(outd + GMPC_LIN_PADROWS) * ldo;
   }
 }
