@@ -262,3 +262,44 @@ def test_unsupported_shape_fails_loudly():
     from gan_mpc_amd.engine import Engine
     with pytest.raises(GmpcError, match="unsupported shape"):
         Engine(376, 17, 50, [393, 200, 200, 200, 376], [376, 128, 128, 10], max_batch=4)
+
+
+def test_nan_trajectory_follows_the_trajax_rules_and_is_isolated():
+    """A poisoned trajectory (NaN control) has a NaN objective; the continuation test
+    `obj_step > obj_step_threshold * (|obj| + 1)` then compares against NaN and is false, so the
+    restated trajax loop never starts for it (0 iterations, NaN kept) -- and its neighbours in the
+    same workgroup are untouched."""
+    pb, pb64, eng = _setup("tiny-ragged", out_scale=0.05)
+    d = eng.to_dev
+    clean = eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]), {"maxiter": 4})
+    U = pb["U"].copy()
+    U[2, 3, 0] = np.nan
+    out = eng.ilqr_solve(d(pb["x0"]), d(U), d(pb["goal"]), {"maxiter": 4})
+    with np.errstate(all="ignore"):
+        ref = orc.ilqr(pb["dyn"], pb["cmlp"], pb["mpc_w"], pb["goal"], pb["x0"], U, {"maxiter": 4})
+    it = out["iterations"].cpu().numpy()
+    assert it[2] == ref[6][2] == 0
+    assert np.isnan(out["obj"].cpu().numpy()[2])
+    keep = np.arange(pb["B"]) != 2
+    for key in ("X", "U", "obj"):
+        np.testing.assert_array_equal(out[key].cpu().numpy()[keep], clean[key].cpu().numpy()[keep])
+    np.testing.assert_array_equal(it[keep], clean["iterations"].cpu().numpy()[keep])
+
+
+def test_bad_calls_fail_loudly():
+    from gan_mpc_amd import GmpcError
+    pb, _, eng = _setup("tiny-ragged")
+    d = eng.to_dev
+    with pytest.raises(GmpcError, match="outside"):
+        eng.rollout_cost(d(pb["x0"][:0]), d(pb["U"][:0]), d(pb["goal"][:0]))       # empty batch
+    big = np.repeat(pb["x0"], 3, axis=0)
+    with pytest.raises(GmpcError, match="outside"):
+        eng.rollout_cost(d(big), d(np.repeat(pb["U"], 3, 0)), d(np.repeat(pb["goal"], 3, 0)))
+    with pytest.raises(GmpcError, match="must precede"):
+        eng.bilevel_grad(3, 0, desired=d(pb["true_seq"][:3]))     # no solve of that batch size yet
+    with pytest.raises(GmpcError, match="make_psd"):
+        eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]), {"make_psd": True})
+    from gan_mpc_amd.engine import Engine
+    e2 = Engine(5, 2, 8, [7, 33, 47, 5], [5, 24, 6], max_batch=4)        # created without a critic
+    with pytest.raises(GmpcError, match="without a critic"):
+        e2.critic_score_vjp(d(pb["true_seq"][:2]), d(np.zeros(8, np.float32)))
