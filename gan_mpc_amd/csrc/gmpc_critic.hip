@@ -11,11 +11,16 @@
 #include "gmpc_device.h"
 
 
-template <int R4>
+// NXR > 0: the input size n is known at compile time and thread j keeps column j of [Wx; Wh]
+// (n + F floats) in registers for the whole sequence -- the weights are read from memory once per
+// workgroup instead of once per time step.  NXR == 0: run-time n, weights streamed from L2 per step.
+template <int R4, int NXR>
 __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd, const float* xseq,
                                                            float* gates, float* cs, float* hp,
                                                            float* hT, int stage_w) {
   constexpr int SB = 4 * R4;
+  constexpr int KC = NXR > 0 ? NXR + 64 : 1;
+  float wreg[KC];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* act = reinterpret_cast<float4*>(smem);            // [(n+F)][R4]
   float4* gbuf = act + (cd.n + cd.F) * R4;                  // [4F][R4]
@@ -36,6 +41,10 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd
   float* gbf = reinterpret_cast<float*>(gbuf);
   for (int e = tid; e < F * SB; e += blockDim.x) actf[n * SB + e] = 0.f;   // h_{-1} = 0
   const float bj = tid < G4 ? cd.b[tid] : 0.f;
+  if (NXR > 0) {
+#pragma unroll
+    for (int k = 0; k < KC; ++k) wreg[k] = tid < G4 ? cd.Wcat[(size_t)k * G4 + tid] : 0.f;
+  }
   for (int t = 0; t < T1; ++t) {
     for (int e = tid; e < n * SB; e += blockDim.x) {
       const int sb = e / n, i = e - sb * n;
@@ -51,8 +60,16 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd
     float4 acc[R4];
 #pragma unroll
     for (int q = 0; q < R4; ++q) acc[q] = make_float4(bj, bj, bj, bj);
-    if (stage_w) dense_rows_lds<R4>(wlds, K, G4, tid, act, acc);
-    else dense_rows<R4>(cd.Wcat, K, G4, tid, act, acc);
+    if (NXR > 0) {
+#pragma unroll
+      for (int k = 0; k < KC; ++k)
+#pragma unroll
+        for (int q = 0; q < R4; ++q) fma4(acc[q], wreg[k], act[k * R4 + q]);
+    } else if (stage_w) {
+      dense_rows_lds<R4>(wlds, K, G4, tid, act, acc);
+    } else {
+      dense_rows<R4>(cd.Wcat, K, G4, tid, act, acc);
+    }
     if (tid < G4) {
       const bool is_g = (tid >= 2 * F) && (tid < 3 * F);
 #pragma unroll
@@ -211,16 +228,21 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_head(int Bc, CriticDesc cd, in
   }
 }
 
-template <int R4>
+template <int R4, int NXR>
 __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd, const float* gates,
                                                            const float* cs, const float* dhT,
                                                            float* dz, float* dxseq, int stage_w) {
   constexpr int SB = 4 * R4;
   constexpr int SPT = SB / 4;
+  // register-resident [Wx; Wh]^T (NXR > 0): thread (j, seg) keeps its K-segment of row j
+  constexpr int KC = NXR > 0 ? NXR + 64 : 1;                 // outputs of the product: [dx ; dh]
+  constexpr int NSEG = NXR > 0 ? GMPC_THREADS / KC : 1;      // K = 4F = 256 split in NSEG segments
+  constexpr int KSG = NXR > 0 ? (256 + NSEG - 1) / NSEG : 1;
+  float wt[KSG];
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* dzb = reinterpret_cast<float4*>(smem);            // [4F][R4]
-  float4* part = dzb + GMPC_THREADS * R4;                   // dense_small scratch / result
-  float* wlds = reinterpret_cast<float*>(part + GMPC_THREADS * R4);   // [4F][(n+F)] when staged
+  float4* part = dzb + (GMPC_THREADS + 128) * R4;           // dense_small scratch / result
+  float* wlds = reinterpret_cast<float*>(part + (GMPC_THREADS + 128) * R4);   // [4F][(n+F)] when staged
   const int tid = threadIdx.x;
   const int n = cd.n, F = cd.F, T1 = cd.T1, G4 = 4 * F, K = n + F;
   const int s0 = blockIdx.x * SB;
@@ -228,6 +250,16 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd
   float* dzf = reinterpret_cast<float*>(dzb);
   if (stage_w)
     for (int e = tid; e < K * G4; e += blockDim.x) wlds[e] = cd.WcatT[e];
+  const int jr = NXR > 0 ? tid % KC : 0, segr = NXR > 0 ? tid / KC : 0;
+  if (NXR > 0) {
+#pragma unroll
+    for (int kk = 0; kk < KSG; ++kk) {
+      const int k = segr * KSG + kk;
+      wt[kk] = (segr < NSEG && k < G4) ? cd.WcatT[(size_t)k * KC + jr] : 0.f;
+    }
+    // rows G4 .. G4+KSG of the dz image are read (times a zero weight) by the last segment
+    for (int e = tid; e < KSG * R4; e += blockDim.x) dzb[G4 * R4 + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   float dh[SPT], dc[SPT];
 #pragma unroll
   for (int e = 0; e < SPT; ++e) {
@@ -263,7 +295,33 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd
     }
     __syncthreads();
     // [dx ; dh_prev][k][sb] = sum_j WcatT[j][k] dz[j][sb]
-    dense_small<R4>(stage_w ? wlds : cd.WcatT, G4, K, dzb, part);
+    if (NXR > 0) {
+      if (segr < NSEG) {
+        float4 acc[R4];
+#pragma unroll
+        for (int q = 0; q < R4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* dseg = dzb + segr * KSG * R4;
+#pragma unroll
+        for (int kk = 0; kk < KSG; ++kk)
+#pragma unroll
+          for (int q = 0; q < R4; ++q) fma4(acc[q], wt[kk], dseg[kk * R4 + q]);
+#pragma unroll
+        for (int q = 0; q < R4; ++q) part[(segr * KC + jr) * R4 + q] = acc[q];
+      }
+      __syncthreads();
+      for (int e = tid; e < KC * R4; e += blockDim.x) {
+        float4 sm = part[e];
+#pragma unroll
+        for (int sg = 1; sg < NSEG; ++sg) {
+          const float4 pp = part[sg * KC * R4 + e];
+          sm.x += pp.x; sm.y += pp.y; sm.z += pp.z; sm.w += pp.w;
+        }
+        part[e] = sm;
+      }
+      __syncthreads();
+    } else {
+      dense_small<R4>(stage_w ? wlds : cd.WcatT, G4, K, dzb, part);
+    }
     const float* pf = reinterpret_cast<const float*>(part);
 #pragma unroll
     for (int e = 0; e < SPT; ++e) dh[e] = pf[(n + u) * SB + grp * SPT + e];
@@ -442,12 +500,19 @@ void gmpc_launch_lstm_fwd(int Bc, const CriticDesc& cd, const float* xseq, float
   if (stage_w) lds += wbytes;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_fwd<R4>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_fwd<R4, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(k_lstm_fwd<R4>, dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates, cs,
-                     hp, hT, stage_w);
+  if (cd.n == 17 && cd.F == 64)
+    hipLaunchKernelGGL((k_lstm_fwd<R4, 17>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates,
+                       cs, hp, hT, 0);
+  else if (cd.n == 3 && cd.F == 64)
+    hipLaunchKernelGGL((k_lstm_fwd<R4, 3>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates,
+                       cs, hp, hT, 0);
+  else
+    hipLaunchKernelGGL((k_lstm_fwd<R4, 0>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates,
+                       cs, hp, hT, stage_w);
 }
 
 void gmpc_launch_head(int Bc, const CriticDesc& cd, int loss_kind, const float* hT,
@@ -465,18 +530,25 @@ void gmpc_launch_lstm_bwd(int Bc, const CriticDesc& cd, const float* gates, cons
                           const float* dhT, float* dz, float* dxseq, hipStream_t s) {
   constexpr int R4 = GMPC_CR4;
   const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
-  size_t lds = 2 * (size_t)GMPC_THREADS * R4 * sizeof(float4);
+  size_t lds = 2 * (size_t)(GMPC_THREADS + 128) * R4 * sizeof(float4);
   const size_t wbytes = (size_t)(cd.n + cd.F) * 4 * cd.F * sizeof(float);
   const int stage_w = 0 * (lds + wbytes <= 150 * 1024);   // no gain measured (see k_lstm_fwd)
   if (stage_w) lds += wbytes;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_bwd<R4>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lstm_bwd<R4, 0>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL(k_lstm_bwd<R4>, dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, gates, cs, dhT,
-                     dz, dxseq, stage_w);
+  if (cd.n == 17 && cd.F == 64)
+    hipLaunchKernelGGL((k_lstm_bwd<R4, 17>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, gates, cs,
+                       dhT, dz, dxseq, 0);
+  else if (cd.n == 3 && cd.F == 64)
+    hipLaunchKernelGGL((k_lstm_bwd<R4, 3>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, gates, cs,
+                       dhT, dz, dxseq, 0);
+  else
+    hipLaunchKernelGGL((k_lstm_bwd<R4, 0>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, gates, cs,
+                       dhT, dz, dxseq, stage_w);
 }
 
 // C[M][N] = sum_r A[r][:M]^T B[r][:N]; colsum[N] = sum_{r < cs_rows} B[r][:N] (optional).
