@@ -263,12 +263,43 @@ __global__ __launch_bounds__(GMPC_RIC_THREADS) void k_riccati(RiccatiArgs a) {
   float gn2 = 0.f;
   __syncthreads();
 
+  // Software prefetch of the next step's inputs (compile-time sizes only): the [A_t | B_t] block,
+  // x_t - goal_t and u_t of step t-1 are requested at the top of step t and land in LDS at its end,
+  // so the recursion never waits for a global-memory round trip.
+  constexpr int PFN = (N_ > 0) ? (N_ * (N_ + M_) + NTH - 1) / NTH : 1;
+  float pf_ab[PFN];
+  float pf_d = 0.f, pf_u = 0.f;
+  auto prefetch = [&](int tp) {
+    const size_t btp = (size_t)b * T + tp;
+#pragma unroll
+    for (int r = 0; r < PFN; ++r) {
+      const int e = lane + r * NTH;
+      pf_ab[r] = e < n * nm ? a.AB[btp * n * nm + e] : 0.f;
+    }
+    if (lane < n)
+      pf_d = a.X[((size_t)b * (T + 1) + tp) * n + lane] - a.goal[((size_t)b * (T + 1) + tp) * n + lane];
+    if (lane < m) pf_u = a.U[btp * m + lane];
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int r = 0; r < PFN; ++r) {
+      const int e = lane + r * NTH;
+      if (e < n * nm) ABs[e] = pf_ab[r];
+    }
+    if (lane < n) dv[lane] = pf_d;
+    if (lane < m) uv[lane] = pf_u;
+  };
+  if (N_ > 0) { prefetch(T - 1); commit(); }
   for (int t = T - 1; t >= 0; --t) {
     const size_t bt = (size_t)b * T + t;
-    for (int e = lane; e < n * nm; e += NTH) ABs[e] = a.AB[bt * n * nm + e];
-    for (int i = lane; i < n; i += NTH)
-      dv[i] = a.X[((size_t)b * (T + 1) + t) * n + i] - a.goal[((size_t)b * (T + 1) + t) * n + i];
-    for (int j = lane; j < m; j += NTH) uv[j] = a.U[bt * m + j];
+    if (N_ > 0) {
+      if (t > 0) prefetch(t - 1);
+    } else {
+      for (int e = lane; e < n * nm; e += NTH) ABs[e] = a.AB[bt * n * nm + e];
+      for (int i = lane; i < n; i += NTH)
+        dv[i] = a.X[((size_t)b * (T + 1) + t) * n + i] - a.goal[((size_t)b * (T + 1) + t) * n + i];
+      for (int j = lane; j < m; j += NTH) uv[j] = a.U[bt * m + j];
+    }
     __syncthreads();
     float dd = 0.f, uu = 0.f;
     _Pragma("unroll") for (int i = 0; i < n; ++i) dd = fmaf(dv[i], dv[i], dd);
@@ -453,6 +484,7 @@ __global__ __launch_bounds__(GMPC_RIC_THREADS) void k_riccati(RiccatiArgs a) {
       P[e] = (AtP[e] + AtP[j * n + i]) * 0.5f;
     }
     for (int i = lane; i < n; i += NTH) pv[i] = tv[i];
+    if (N_ > 0 && t > 0) commit();   // ABs / dv / uv of this step are dead: install step t-1
     __syncthreads();
   }
 
