@@ -20,7 +20,8 @@ void gmpc_launch_masks(int, int, int, int, const MlpDesc&, const float*, const f
 int gmpc_launch_linearize(int, int, int, int, const MlpDesc&, const uint32_t*, const int*, float*,
                           hipStream_t);
 int gmpc_launch_linearize_mfma(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
-                               const int*, float*, hipStream_t);
+                               const int*, float*, int, int, hipStream_t);
+void gmpc_launch_bgemm_tn(const BgemmArgs&, hipStream_t);
 size_t gmpc_linpad_floats(const gmpc_shape*);
 void gmpc_linpad_prepare(const MlpDesc&, int, int, float*, size_t, LinPad*, hipStream_t);
 int gmpc_launch_terminal(int, int, int, const MlpDesc&, const float*, const float*, const int*,
@@ -314,6 +315,7 @@ extern "C" int gmpc_set_params(gmpc_ctx* c, const float* mpc_w, const float* dyn
   if (!c || !mpc_w || !dyn || !cost) return fail(GMPC_EINVAL, "null argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
   HIP_TRY(hipSetDevice(c->device));
+  (void)hipGetLastError();   // clean slate (see check_call)
   c->mpc_w = mpc_w;
   bind_mlp(c->dyn, c->sh.dyn_layers, c->sh.dyn_dims, dyn, c->dynT);
   bind_mlp(c->cost, c->sh.cost_layers, c->sh.cost_dims, cost, c->costT);
@@ -334,6 +336,10 @@ static int check_call(gmpc_ctx* c, int B) {
   if (!c->params_set) return fail(GMPC_EINVAL, "gmpc_set_params has not been called");
   if (B < 1 || B > c->maxB) return fail(GMPC_EINVAL, "B=%d outside [1, max_batch=%d]", B, c->maxB);
   if (hipSetDevice(c->device) != hipSuccess) return fail(GMPC_EHIP, "hipSetDevice failed");
+  // hipGetLastError() is per-thread and shared with every other HIP user of the process (torch
+  // leaves benign errors behind): start every entry point from a clean slate so that the checks
+  // after our launches report only our own failures
+  (void)hipGetLastError();
   return 0;
 }
 
@@ -374,16 +380,19 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
       return e && strcmp(e, "valu") == 0;
     }();
     if (force_valu ||
-        gmpc_launch_linearize_mfma(B, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active, AB, s) != 0) {
+        gmpc_launch_linearize_mfma(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active, AB, 1, 0,
+                                   s) != 0) {
       if (gmpc_launch_linearize(B, sh.T, sh.n, sh.m, c->dyn, c->masks, active, AB, s) != 0)
         return fail(GMPC_EINVAL, "linearize: unsupported row count for n=%d", sh.n);
     }
   }
+  HIP_TRY(hipGetLastError());
   {
     ProfScope ps(c, PROF_TERMINAL, s);
     if (gmpc_launch_terminal(B, sh.T, sh.n, c->cost, c->mpc_w, X, active, c->QT, c->qT, s) != 0)
       return fail(GMPC_EINVAL, "terminal: unsupported fout");
   }
+  HIP_TRY(hipGetLastError());
   RiccatiArgs r;
   memset(&r, 0, sizeof(r));
   r.B = B; r.n = sh.n; r.m = sh.m; r.T = sh.T; r.mode = 0;
@@ -554,6 +563,7 @@ extern "C" int gmpc_critic_loss_grad(gmpc_ctx* c, int Bc, const float* xseq, con
   if (Bc < 1 || Bc > 2 * c->maxB) return fail(GMPC_EINVAL, "Bc=%d outside [1, 2*max_batch]", Bc);
   if (!xseq || !label || !critic || !loss_sum || !grad_sum) return fail(GMPC_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(c->device));
+  (void)hipGetLastError();   // clean slate (see check_call)
   hipStream_t s = static_cast<hipStream_t>(stream);
   TRY(critic_forward_backward(c, Bc, xseq, label, critic, 0, nullptr, true, grad_sum, s));
   gmpc_launch_sum(Bc, c->closs, loss_sum, 0, s);
@@ -567,6 +577,7 @@ extern "C" int gmpc_critic_score_vjp(gmpc_ctx* c, int Bc, const float* xseq, con
   if (Bc < 1 || Bc > 2 * c->maxB) return fail(GMPC_EINVAL, "Bc=%d outside [1, 2*max_batch]", Bc);
   if (!xseq || !critic || !score) return fail(GMPC_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(c->device));
+  (void)hipGetLastError();   // clean slate (see check_call)
   hipStream_t s = static_cast<hipStream_t>(stream);
   TRY(critic_forward_backward(c, Bc, xseq, nullptr, critic, 2, dxseq, false, nullptr, s));
   HIP_TRY(hipMemcpyAsync(score, c->cscore, Bc * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -605,6 +616,7 @@ extern "C" int gmpc_polyak(gmpc_ctx* c, long count, const float* prev, const flo
                            float* out, void* stream) {
   if (!c || !prev || !cur || !out || count < 1) return fail(GMPC_EINVAL, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
+  (void)hipGetLastError();   // clean slate (see check_call)
   gmpc_launch_polyak(count, prev, cur, factor, out, static_cast<hipStream_t>(stream));
   HIP_TRY(hipGetLastError());
   return 0;
@@ -653,12 +665,32 @@ extern "C" int gmpc_adam_clip_step(gmpc_ctx* c, long count, float* params, const
   if (!c || !params || !grad || !m || !v) return fail(GMPC_EINVAL, "null argument");
   if (count < 1 || step < 1) return fail(GMPC_EINVAL, "count and step must be positive");
   HIP_TRY(hipSetDevice(c->device));
+  (void)hipGetLastError();   // clean slate (see check_call)
   hipStream_t s = static_cast<hipStream_t>(stream);
   {
     ProfScope ps(c, PROF_ADAM, s);
     gmpc_launch_adam(count, params, grad, m, v, grad_scale, step, lr, max_norm, b1, b2, eps,
                      c->scratch, s);
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Batched TN GEMM used by the large-state Riccati path, exported for its unit test:
+// C[b] = alpha * X[b]^T Y[b] + beta * C[b] with X[b] K x M, Y[b] K x N, C[b] M x N, all row-major
+// and densely packed per batch element.  Y must be followed by >= 8 readable rows.
+extern "C" int gmpc_bgemm_tn(gmpc_ctx* c, int batch, int M, int N, int K, const float* X, const float* Y,
+                             float* C, float alpha, float beta, void* stream) {
+  if (!c || !X || !Y || !C || batch < 1 || M < 1 || N < 1 || K < 1) return fail(GMPC_EINVAL, "bad argument");
+  HIP_TRY(hipSetDevice(c->device));
+  (void)hipGetLastError();   // clean slate (see check_call)
+  BgemmArgs a;
+  a.batch = batch; a.M = M; a.N = N; a.K = K;
+  a.X = X; a.sx = (long)K * M; a.ldx = M;
+  a.Y = Y; a.sy = (long)K * N; a.ldy = N;
+  a.C = C; a.sc = (long)M * N; a.ldc = N;
+  a.alpha = alpha; a.beta = beta; a.active = nullptr;
+  gmpc_launch_bgemm_tn(a, static_cast<hipStream_t>(stream));
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -673,6 +705,7 @@ extern "C" int gmpc_profile_read(gmpc_ctx* c, int slot, double* total_ms, int* c
   if (!c || slot < 0 || slot >= GMPC_PROF_SLOTS || !total_ms || !count)
     return fail(GMPC_EINVAL, "bad argument");
   HIP_TRY(hipSetDevice(c->device));
+  (void)hipGetLastError();   // clean slate (see check_call)
   double tot = 0.0;
   int n = 0;
   for (auto& pr : c->prof_ev[slot]) {

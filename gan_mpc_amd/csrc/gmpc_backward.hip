@@ -110,9 +110,10 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_terminal(int B, int T, int n, 
                                                            const float* mpc_w, const float* X,
                                                            const int* active, float* QT, float* qT) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bw = (n > GMPC_THREADS ? n : GMPC_THREADS) * R4;        // float4 per buffer
   float4* actA = reinterpret_cast<float4*>(smem);
-  float4* actB = actA + GMPC_THREADS * R4;
-  float* zpos = reinterpret_cast<float*>(actB + GMPC_THREADS * R4);  // [Lc][256] relu masks
+  float4* actB = actA + bw;
+  float* zpos = reinterpret_cast<float*>(actB + bw);                 // [Lc][256] relu masks
   float* yv = zpos + GMPC_MAX_LAYERS * GMPC_THREADS;                 // [fout]
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_terminal(int B, int T, int n, 
   // forward (component .x only)
   float4* in = actA;
   float4* out = actB;
-  if (tid < n) in[tid] = make_float4(X[((size_t)b * (T + 1) + T) * n + tid], 0.f, 0.f, 0.f);
+  for (int i = tid; i < n; i += blockDim.x)
+    in[i] = make_float4(X[((size_t)b * (T + 1) + T) * n + i], 0.f, 0.f, 0.f);
   __syncthreads();
   for (int l = 0; l < Lc; ++l) {
     const int K = cm.dims[l], N = cm.dims[l + 1];
@@ -182,8 +184,21 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_terminal(int B, int T, int n, 
     float4* tmp = in; in = out; out = tmp;
   }
   // Jc[r][i] = sum_o act[o][r] W_1[i][o]   ->  out[i*R4 + r/4].(r%4)
-  if (Lc > 0) {
+  if (Lc > 0 && n <= (int)blockDim.x) {
     dense_small<R4>(cm.WT[0], cm.dims[1], n, in, out);
+  } else if (Lc > 0) {
+    // wide state: one input coordinate per thread, chunk after chunk
+    for (int jb = 0; jb < n; jb += blockDim.x) {
+      float4 acc[R4];
+#pragma unroll
+      for (int q = 0; q < R4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dense_rows<R4>(cm.WT[0], cm.dims[1], n, jb + tid, in, acc);
+      if (jb + tid < n) {
+#pragma unroll
+        for (int q = 0; q < R4; ++q) out[(jb + tid) * R4 + q] = acc[q];
+      }
+    }
+    __syncthreads();
   } else {
     // single Dense layer: Jc[r][i] = W[i][r]
     for (int e = tid; e < n * R4; e += blockDim.x) {
@@ -203,10 +218,10 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_terminal(int B, int T, int n, 
     for (int r = 0; r < fo; ++r) s = fmaf(J[i * RS + r], J[k * RS + r], s);
     QT[(size_t)b * n * n + e] = 2.f * w2 * s;
   }
-  if (tid < n) {
+  for (int i = tid; i < n; i += blockDim.x) {
     float s = 0.f;
-    for (int r = 0; r < fo; ++r) s = fmaf(J[tid * RS + r], yv[r], s);
-    qT[(size_t)b * n + tid] = 2.f * w2 * s;
+    for (int r = 0; r < fo; ++r) s = fmaf(J[i * RS + r], yv[r], s);
+    qT[(size_t)b * n + i] = 2.f * w2 * s;
   }
 }
 
@@ -588,8 +603,10 @@ int gmpc_launch_terminal(int B, int T, int n, const MlpDesc& cm, const float* mp
   switch (R4) {
 #define GMPC_TERM_CASE(q)                                                                          \
   case q:                                                                                          \
-    lds = 2 * (size_t)GMPC_THREADS * q * sizeof(float4) +                                          \
+    lds = 2 * (size_t)(n > GMPC_THREADS ? n : GMPC_THREADS) * q * sizeof(float4) +                 \
           (GMPC_MAX_LAYERS * GMPC_THREADS + 64) * sizeof(float);                                   \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_terminal<q>),                      \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);             \
     hipLaunchKernelGGL(k_terminal<q>, dim3(B), dim3(GMPC_THREADS), lds, s, B, T, n, cm, mpc_w, X,  \
                        active, QT, qT);                                                            \
     return 0;

@@ -170,6 +170,7 @@ struct TrajArgs {
   float* U_step;        // [B] out
   int* iters;           // [B] in/out
   float alpha_0, alpha_min;
+  int aw, pw;           // LDS sizing (float4 counts): activation buffers, partial-sum buffer
 };
 
 struct RiccatiArgs {
@@ -196,9 +197,19 @@ struct CriticDesc {
   MlpDesc head;              // dims[0] = F ... dims[L] = 1
 };
 
+// batched "TN" GEMM of the large-state path (gmpc_large.hip)
+struct BgemmArgs {
+  int batch, M, N, K;
+  const float* X; long sx; int ldx;     // X[b]: K x M row-major (leading dim ldx), batch stride sx
+  const float* Y; long sy; int ldy;     // Y[b]: K x N
+  float* C; long sc; int ldc;           // C[b]: M x N
+  float alpha, beta;
+  const int* active;                    // [batch] or null
+};
+
 // zero-padded weight copies read by the MFMA Jacobian chain (gmpc_linearize_mfma.hip)
 struct LinPad {
-  int NT, NTF;                          // column tiles of the hidden GEMMs / of the input GEMM
+  int NT, NTF, NGF;                     // column tiles: hidden GEMMs / input GEMM per group, groups
   const float* WLP;                     // [dims[Lh]+2][n]            rows >= dims[Lh] are zero
   const float* WTP[GMPC_MAX_LAYERS];    // l>=1: [dims[l+1]+2][32*NT]; l==0: [dims[1]+2][32*NTF]
   unsigned long long* dbg;              // diagnostic: per-segment cycle sums (null in production)

@@ -40,16 +40,21 @@ __global__ void k_pad_transpose_x4(int in, int out, const float* W, float* dst) 
 
 template <int NT, int NTF>
 __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
-    int B, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
-    float* AB, int ntiles, int nsmax, int stage_wl, int stage_w1) {
+    int NSamp, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
+    float* AB, int ntiles, int nsmax, int stage_wl, int stage_w1, int samp_mul, int samp_add) {
+  // sample s of this launch is sample s*samp_mul + samp_add of the masks / trajectory s_id / T of
+  // `active` (the whole batch: mul 1, add 0; one time step t of every trajectory: mul T, add t)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SK = 32 * NT + 1;
   constexpr int NP = 32 * NT;
-  constexpr int NPF = 32 * NTF;
+  constexpr int NGW = 32 * NTF;                 // columns per group of the input GEMM
+  constexpr bool ONEG = NTF <= 3;               // NTF <= 3 always means a single group
+  const int NGF = ONEG ? 1 : lp.NGF;
+  const int NPF = ONEG ? NGW : NGW * lp.NGF;    // padded row length of W_1^T (compile-time if ONEG)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int Lh = dyn.L - 1;
   const int nm = n + m;
-  const int Rtot = B * T * n;
+  const int Rtot = NSamp * n;
   const size_t wave_bytes =
       (size_t)(32 * SK + 8) * sizeof(float) + (size_t)Lh * nsmax * GMPC_MW * sizeof(uint32_t);
   float* G = reinterpret_cast<float*>(smem + wave * wave_bytes);
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
   // workgroup-shared copies of the two small operands (when they fit): W_L and the padded W_1^T
   float* sh = reinterpret_cast<float*>(smem + (GMPC_THREADS / 64) * wave_bytes);
   const int wl_floats = (dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;
-  const int w1_floats = (dyn.dims[1] + GMPC_LIN_PADROWS) * NPF;
+  const int w1_floats = (dyn.dims[1] + GMPC_LIN_PADROWS) * NPF;   // staged only when NGF == 1
   float* wl_s = sh;
   float* w1_s = sh + (stage_wl ? wl_floats : 0);
   if (stage_wl)
@@ -84,14 +89,15 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
     const int ns = s_hi - s_lo + 1;
     if (active != nullptr) {
       bool any = false;
-      for (int s = s_lo; s <= s_hi; ++s) any |= active[s / T] != 0;
+      for (int s = s_lo; s <= s_hi; ++s) any |= active[(s * samp_mul + samp_add) / T] != 0;
       if (!any) continue;
     }
     // ---- relu bit words of the tile's samples -> LDS
     for (int e = lane; e < Lh * ns * GMPC_MW; e += 64) {
       const int l = e / (ns * GMPC_MW), rem = e - l * ns * GMPC_MW;
       const int si = rem / GMPC_MW, w = rem - si * GMPC_MW;
-      mk[(l * nsmax + si) * GMPC_MW + w] = masks[((size_t)(s_lo + si) * Lh + l) * GMPC_MW + w];
+      const size_t sid = (size_t)(s_lo + si) * samp_mul + samp_add;
+      mk[(l * nsmax + si) * GMPC_MW + w] = masks[(sid * Lh + l) * GMPC_MW + w];
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
@@ -167,8 +173,8 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
       __builtin_amdgcn_wave_barrier();
       GMPC_STAMP(2)
     }
-    // ================= input GEMM (l = 0): N = n + m columns, NTF tiles =================
-    {
+    // ================= input GEMM (l = 0): N = n + m columns in NGF groups of NTF tiles ===========
+    for (int cg = 0; cg < NGF; ++cg) {
       const int K = dyn.dims[1];
       const int Kp = (K + 1) & ~1;
       f32x16 acc0[NTF];
@@ -176,8 +182,8 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
       for (int nt = 0; nt < NTF; ++nt)
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) acc0[nt][rg] = 0.f;
-      const float* bp_g = lp.WTP[0] + (size_t)half * NPF + l31;
-      const float* bp_l = w1_s + half * NPF + l31;
+      const float* bp_g = lp.WTP[0] + (size_t)half * NPF + cg * NGW + l31;
+      const float* bp_l = w1_s + half * NPF + l31;      // staged only when NGF == 1
       mrow = mk + (0 * nsmax + sa) * GMPC_MW;   // relu bits of hidden layer 0 (k index of this GEMM)
       if (Lh == 1) {
         // single hidden layer: the seed tile feeds the input GEMM directly
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
       GMPC_STAMP(3)
 #pragma unroll
       for (int nt = 0; nt < NTF; ++nt) {
-        const int c = nt * 32 + l31;
+        const int c = cg * NGW + nt * 32 + l31;
         if (c < nm) {
 #pragma unroll
           for (int rg = 0; rg < 16; ++rg) {
@@ -233,9 +239,10 @@ size_t gmpc_linpad_floats(const gmpc_shape* sh) {
   const int L = sh->dyn_layers, Lh = L - 1;
   int wmax = 1;
   for (int l = 1; l < L; ++l) wmax = sh->dyn_dims[l] > wmax ? sh->dyn_dims[l] : wmax;
-  const int NT = (wmax + 31) / 32, NTF = (sh->n + sh->m + 31) / 32;
+  const int tilesF = (sh->n + sh->m + 31) / 32;
+  const int NTF = tilesF <= 3 ? tilesF : 8, NGF = (tilesF + NTF - 1) / NTF;
   size_t f = (size_t)(sh->dyn_dims[Lh] + GMPC_LIN_PADROWS) * sh->n;
-  f += (size_t)(sh->dyn_dims[1] + GMPC_LIN_PADROWS) * 32 * NTF;
+  f += (size_t)(sh->dyn_dims[1] + GMPC_LIN_PADROWS) * 32 * NTF * NGF;
   for (int l = 1; l < Lh; ++l) f += (size_t)(sh->dyn_dims[l + 1] + GMPC_LIN_PADROWS) * 256;
   return f + 64;
 }
@@ -247,7 +254,9 @@ void gmpc_linpad_prepare(const MlpDesc& dyn, int n, int m, float* pad, size_t pa
   int wmax = 1;
   for (int l = 1; l < dyn.L; ++l) wmax = dyn.dims[l] > wmax ? dyn.dims[l] : wmax;
   out->NT = (wmax + 31) / 32;
-  out->NTF = (n + m + 31) / 32;
+  const int tilesF = (n + m + 31) / 32;
+  out->NTF = tilesF <= 3 ? tilesF : 8;
+  out->NGF = (tilesF + out->NTF - 1) / out->NTF;
   out->dbg = nullptr;
   (void)hipMemsetAsync(pad, 0, pad_floats * sizeof(float), s);
   float* p = pad;
@@ -257,7 +266,7 @@ void gmpc_linpad_prepare(const MlpDesc& dyn, int n, int m, float* pad, size_t pa
   p += (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;
   for (int l = 0; l < Lh; ++l) {
     const int in = dyn.dims[l], outd = dyn.dims[l + 1];
-    const int ldo = (l == 0) ? 32 * out->NTF : 256;
+    const int ldo = (l == 0) ? 32 * out->NTF * out->NGF : 256;
     out->WTP[l] = p;
     const int cnt = in * outd;
     if (l == 0)
@@ -271,9 +280,10 @@ void gmpc_linpad_prepare(const MlpDesc& dyn, int n, int m, float* pad, size_t pa
 }
 
 template <int NT, int NTF>
-static int launch_mfma(int B, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
-                       const uint32_t* masks, const int* active, float* AB, hipStream_t s) {
-  const long Rtot = (long)B * T * n;
+static int launch_mfma(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
+                       const uint32_t* masks, const int* active, float* AB, int samp_mul, int samp_add,
+                       hipStream_t s) {
+  const long Rtot = (long)NSamp * n;
   if (Rtot >= (1L << 31) - 64) return -1;
   const int ntiles = (int)((Rtot + 31) / 32);
   const int nsmax = 32 / n + 2;
@@ -285,10 +295,10 @@ static int launch_mfma(int B, int T, int n, int m, const MlpDesc& dyn, const Lin
   if (lds > lds_max) return -1;
   // stage the two small operands in LDS when they fit (W_1^T first: its GEMM has one MFMA per
   // k-step and is latency-bound from L2)
-  const size_t w1_bytes = (size_t)(dyn.dims[1] + GMPC_LIN_PADROWS) * 32 * NTF * sizeof(float);
+  const size_t w1_bytes = (size_t)(dyn.dims[1] + GMPC_LIN_PADROWS) * 32 * NTF * lp.NGF * sizeof(float);
   const size_t wl_bytes = (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n * sizeof(float);
   int stage_w1 = 0, stage_wl = 0;
-  if (lds + w1_bytes <= lds_max) { stage_w1 = 1; lds += w1_bytes; }
+  if (lp.NGF == 1 && lds + w1_bytes <= lds_max) { stage_w1 = 1; lds += w1_bytes; }
   if (lds + wl_bytes <= lds_max) { stage_wl = 1; lds += wl_bytes; }
   static bool attr_set = false;
   if (!attr_set) {
@@ -298,19 +308,24 @@ static int launch_mfma(int B, int T, int n, int m, const MlpDesc& dyn, const Lin
   }
   int grid = (ntiles + 3) / 4;
   if (grid > 256) grid = 256;   // one persistent workgroup per CU (LDS-limited to 1 anyway)
-  hipLaunchKernelGGL((k_linearize_mfma<NT, NTF>), dim3(grid), dim3(GMPC_THREADS), lds, s, B, T, n, m,
-                     dyn, lp, masks, active, AB, ntiles, nsmax, stage_wl, stage_w1);
+  hipLaunchKernelGGL((k_linearize_mfma<NT, NTF>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
+                     dyn, lp, masks, active, AB, ntiles, nsmax, stage_wl, stage_w1, samp_mul, samp_add);
   return 0;
 }
 
+// Jacobians of NSamp samples; sample s is sample s*samp_mul + samp_add of `masks`.
 // returns 0 on launch, -1 if the shape does not fit this kernel (caller uses the VALU chain)
-int gmpc_launch_linearize_mfma(int B, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
-                               const uint32_t* masks, const int* active, float* AB, hipStream_t s) {
-#define GMPC_LM(a, b) \
-  if (lp.NT == a && lp.NTF == b) return launch_mfma<a, b>(B, T, n, m, dyn, lp, masks, active, AB, s);
+int gmpc_launch_linearize_mfma(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
+                               const uint32_t* masks, const int* active, float* AB, int samp_mul,
+                               int samp_add, hipStream_t s) {
+#define GMPC_LM(a, b)                                                                              \
+  if (lp.NT == a && lp.NTF == b)                                                                   \
+    return launch_mfma<a, b>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
   GMPC_LM(1, 1) GMPC_LM(2, 1) GMPC_LM(3, 1) GMPC_LM(4, 1) GMPC_LM(5, 1) GMPC_LM(6, 1) GMPC_LM(7, 1)
-  GMPC_LM(8, 1) GMPC_LM(2, 2) GMPC_LM(3, 2) GMPC_LM(4, 2) GMPC_LM(5, 2) GMPC_LM(6, 2) GMPC_LM(7, 2)
-  GMPC_LM(8, 2) GMPC_LM(3, 3) GMPC_LM(4, 3) GMPC_LM(7, 3) GMPC_LM(8, 3)
+  GMPC_LM(8, 1) GMPC_LM(1, 2) GMPC_LM(2, 2) GMPC_LM(3, 2) GMPC_LM(4, 2) GMPC_LM(5, 2) GMPC_LM(6, 2)
+  GMPC_LM(7, 2) GMPC_LM(8, 2) GMPC_LM(1, 3) GMPC_LM(2, 3) GMPC_LM(3, 3) GMPC_LM(4, 3) GMPC_LM(5, 3)
+  GMPC_LM(6, 3) GMPC_LM(7, 3) GMPC_LM(8, 3) GMPC_LM(1, 8) GMPC_LM(2, 8) GMPC_LM(3, 8) GMPC_LM(4, 8)
+  GMPC_LM(5, 8) GMPC_LM(6, 8) GMPC_LM(7, 8) GMPC_LM(8, 8)
 #undef GMPC_LM
   return -1;
 }

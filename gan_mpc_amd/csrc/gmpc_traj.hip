@@ -61,11 +61,13 @@ __device__ __forceinline__ void hidden_layer(const float* W, const float* bias, 
 
 template <bool LS>
 __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
-  __shared__ float4 actA[GMPC_THREADS];
-  __shared__ float4 actB[GMPC_THREADS];
-  __shared__ float4 part[GMPC_TRAJ_THREADS];
-  __shared__ float4 ksp[GMPC_THREADS];
-  __shared__ float4 xcur[64];
+  // dynamic LDS: actA | actB (aw float4 each: max(n+m, widest layer)) | part (pw) | ksp (256) | xcur (n)
+  extern __shared__ __attribute__((aligned(16))) char smem_traj[];
+  float4* const actA = reinterpret_cast<float4*>(smem_traj);
+  float4* const actB = actA + a.aw;
+  float4* const part = actB + a.aw;
+  float4* const ksp = part + a.pw;
+  float4* const xcur = ksp + GMPC_THREADS;
   __shared__ float s_obj[GMPC_TB], s_objold[GMPC_TB], s_alpha[GMPC_TB], s_ustep[GMPC_TB];
   __shared__ float s_us[GMPC_TRAJ_THREADS / 64];
   __shared__ int s_run[GMPC_TB], s_acc[GMPC_TB], s_ever[GMPC_TB], s_any;
@@ -113,16 +115,16 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) wbits |= ((LS ? (s_run[c] != 0) : INB(c)) ? 1u : 0u) << c;
     // ---- initial state
-    if (tid < n) {
+    for (int i = tid; i < n; i += blockDim.x) {
       const float* xs = LS ? a.X : a.x0;
       const size_t st = LS ? (size_t)(T + 1) * n : (size_t)n;
-      float4 v = make_float4(xs[BI(0) * st + tid], xs[BI(1) * st + tid], xs[BI(2) * st + tid],
-                             xs[BI(3) * st + tid]);
-      xcur[tid] = v;
+      float4 v = make_float4(xs[BI(0) * st + i], xs[BI(1) * st + i], xs[BI(2) * st + i],
+                             xs[BI(3) * st + i]);
+      xcur[i] = v;
       if (!LS) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if (INB(c)) a.X[(size_t)BI(c) * (T + 1) * n + tid] = f4get(v, c);
+          if (INB(c)) a.X[(size_t)BI(c) * (T + 1) * n + i] = f4get(v, c);
       }
     }
     float objacc = 0.f;  // lane 0 of wave c accumulates trajectory c
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
 
     for (int t = 0; t < T; ++t) {
       // ---- controls and layer-0 input
-      if (tid < n) actA[tid] = xcur[tid];
+      for (int i = tid; i < n; i += blockDim.x) actA[i] = xcur[i];
       if (tid < GMPC_TB * m) {
         const int c = tid / m, j = tid % m;
         const int bc = BI(c);
@@ -182,18 +184,28 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
         float4* tmp = in; in = out; out = tmp;
       }
       // ---- output layer + residual
-      dense_small<1>(a.dyn.W[Lh], a.dyn.dims[Lh], n, in, part);
-      if (tid < n) {
-        const float bj = a.dyn.b[Lh][tid];
-        float4 v = part[tid];
-        const float4 xo = xcur[tid];
+      if (n <= (int)blockDim.x) {
+        dense_small<1>(a.dyn.W[Lh], a.dyn.dims[Lh], n, in, part);
+      } else {
+        // wide state (n > 512): one output per thread, chunk after chunk
+        for (int jb = 0; jb < n; jb += blockDim.x) {
+          float4 acc[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+          dense_rows<1>(a.dyn.W[Lh], a.dyn.dims[Lh], n, jb + tid, in, acc);
+          if (jb + tid < n) part[jb + tid] = acc[0];
+        }
+        __syncthreads();
+      }
+      for (int i = tid; i < n; i += blockDim.x) {
+        const float bj = a.dyn.b[Lh][i];
+        float4 v = part[i];
+        const float4 xo = xcur[i];
         v.x = (v.x + bj) + xo.x; v.y = (v.y + bj) + xo.y;
         v.z = (v.z + bj) + xo.z; v.w = (v.w + bj) + xo.w;
-        xcur[tid] = v;
+        xcur[i] = v;
         float* Xo = LS ? a.Xc : a.X;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if ((wbits >> c) & 1u) Xo[((size_t)BI(c) * (T + 1) + t + 1) * n + tid] = f4get(v, c);
+          if ((wbits >> c) & 1u) Xo[((size_t)BI(c) * (T + 1) + t + 1) * n + i] = f4get(v, c);
       }
       __syncthreads();
     }
@@ -303,25 +315,26 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
 // trajectory that did not come from this context's rollout.  4 samples per workgroup.
 __global__ __launch_bounds__(GMPC_THREADS) void k_masks(int NS, int n, int m, int T, MlpDesc dyn,
                                                         const float* X, const float* U,
-                                                        uint32_t* masks) {
-  __shared__ float4 actA[GMPC_THREADS];
-  __shared__ float4 actB[GMPC_THREADS];
+                                                        uint32_t* masks, int aw) {
+  extern __shared__ __attribute__((aligned(16))) char smem_masks[];
+  float4* const actA = reinterpret_cast<float4*>(smem_masks);
+  float4* const actB = actA + aw;
   const int tid = threadIdx.x;
   const int s0 = blockIdx.x * 4;
   unsigned wbits = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) wbits |= ((s0 + c < NS) ? 1u : 0u) << c;
-  if (tid < n + m) {
+  for (int i = tid; i < n + m; i += blockDim.x) {
     float4 v;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int si = (s0 + c < NS) ? s0 + c : NS - 1;
       const int b = si / T, t = si % T;
-      const float x = tid < n ? X[((size_t)b * (T + 1) + t) * n + tid]
-                              : U[((size_t)b * T + t) * m + (tid - n)];
+      const float x = i < n ? X[((size_t)b * (T + 1) + t) * n + i]
+                            : U[((size_t)b * T + t) * m + (i - n)];
       f4set(v, c, x);
     }
-    actA[tid] = v;
+    actA[i] = v;
   }
   __syncthreads();
   const int Lh = dyn.L - 1;
@@ -336,17 +349,46 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_masks(int NS, int n, int m, in
 }
 
 // Host-side launchers ---------------------------------------------------------------------------
-void gmpc_launch_rollout(const TrajArgs& a, hipStream_t s) {
-  const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
-  hipLaunchKernelGGL(k_traj<false>, dim3(grid), dim3(GMPC_TRAJ_THREADS), 0, s, a);
+static int traj_aw(int n, int m, const MlpDesc& d1, const MlpDesc* d2) {
+  int w = n + m > GMPC_THREADS ? n + m : GMPC_THREADS;
+  for (int l = 0; l <= d1.L; ++l) w = d1.dims[l] > w ? d1.dims[l] : w;
+  if (d2) for (int l = 0; l <= d2->L; ++l) w = d2->dims[l] > w ? d2->dims[l] : w;
+  return (w + 3) & ~3;
 }
-void gmpc_launch_linesearch(const TrajArgs& a, hipStream_t s) {
+static size_t traj_lds(TrajArgs& a) {
+  a.aw = traj_aw(a.n, a.m, a.dyn, &a.cost);
+  a.pw = a.n > GMPC_TRAJ_THREADS ? a.n : GMPC_TRAJ_THREADS;
+  return ((size_t)2 * a.aw + a.pw + GMPC_THREADS + a.n) * sizeof(float4);
+}
+// dynamic LDS above the default 64 KB needs the attribute; the kernels also hold a few hundred bytes
+// of static LDS, so the full 160 KB cannot be requested
+template <typename KernelT>
+static void traj_attr(KernelT k) {
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            128 * 1024);
+  (void)hipGetLastError();
+}
+
+void gmpc_launch_rollout(const TrajArgs& a0, hipStream_t s) {
+  TrajArgs a = a0;
+  const size_t lds = traj_lds(a);
+  static bool attr = false;
+  if (!attr) { traj_attr(&k_traj<false>); attr = true; }
   const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
-  hipLaunchKernelGGL(k_traj<true>, dim3(grid), dim3(GMPC_TRAJ_THREADS), 0, s, a);
+  hipLaunchKernelGGL(k_traj<false>, dim3(grid), dim3(GMPC_TRAJ_THREADS), lds, s, a);
+}
+void gmpc_launch_linesearch(const TrajArgs& a0, hipStream_t s) {
+  TrajArgs a = a0;
+  const size_t lds = traj_lds(a);
+  static bool attr = false;
+  if (!attr) { traj_attr(&k_traj<true>); attr = true; }
+  const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
+  hipLaunchKernelGGL(k_traj<true>, dim3(grid), dim3(GMPC_TRAJ_THREADS), lds, s, a);
 }
 void gmpc_launch_masks(int B, int n, int m, int T, const MlpDesc& dyn, const float* X,
                        const float* U, uint32_t* masks, hipStream_t s) {
   const int NS = B * T;
-  hipLaunchKernelGGL(k_masks, dim3((NS + 3) / 4), dim3(GMPC_THREADS), 0, s, NS, n, m, T, dyn, X, U,
-                     masks);
+  const int aw = traj_aw(n, m, dyn, nullptr);
+  hipLaunchKernelGGL(k_masks, dim3((NS + 3) / 4), dim3(GMPC_THREADS), 2 * (size_t)aw * sizeof(float4), s,
+                     NS, n, m, T, dyn, X, U, masks, aw);
 }

@@ -158,6 +158,13 @@ int gmpc_adam_clip_step(gmpc_ctx* ctx, long count, float* params, const float* g
                         float* v, float grad_scale, int step, double lr, double max_norm, double b1,
                         double b2, double eps, void* stream);
 
+/* Building block of the large-state (n > 64) Riccati path, exported for its unit test: batched
+ * C[b] = alpha * X[b]^T Y[b] + beta * C[b] on the fp32 matrix cores; X[b] is K x M, Y[b] K x N,
+ * C[b] M x N, row-major, densely packed per batch element; Y must be followed by >= 8 readable rows
+ * of N floats. */
+int gmpc_bgemm_tn(gmpc_ctx* ctx, int batch, int M, int N, int K, const float* X, const float* Y,
+                  float* C, float alpha, float beta, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the launch stream around each kernel
  * (bench.py's roofline leg).  Slots: 0 rollout, 1 linearize, 2 terminal, 3 riccati, 4 linesearch,
  * 5 lstm_fwd, 6 head, 7 lstm_bwd, 8 wgrad (all weight-gradient GEMMs of one critic call), 9 adam.

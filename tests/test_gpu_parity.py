@@ -303,3 +303,24 @@ def test_bad_calls_fail_loudly():
     e2 = Engine(5, 2, 8, [7, 33, 47, 5], [5, 24, 6], max_batch=4)        # created without a critic
     with pytest.raises(GmpcError, match="without a critic"):
         e2.critic_score_vjp(d(pb["true_seq"][:2]), d(np.zeros(8, np.float32)))
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(376, 376, 376, 3), (17, 376, 376, 2), (376, 17, 17, 2),
+                                         (40, 70, 33, 5), (64, 1024, 129, 1)])
+def test_bgemm_tn_matches_float64(M, N, K, batch):
+    """building block of the large-state Riccati path: C = alpha X^T Y + beta C"""
+    import ctypes as C
+    from gan_mpc_amd import _lib
+    pb, _, eng = _setup("tiny-ragged")
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((batch, K, M)).astype(np.float32)
+    Y = np.zeros((batch * K + 8, N), np.float32)           # 8 readable pad rows
+    Y[:batch * K] = rng.standard_normal((batch * K, N))
+    C0 = rng.standard_normal((batch, M, N)).astype(np.float32)
+    Xd, Yd, Cd = eng.to_dev(X), eng.to_dev(Y), eng.to_dev(C0)
+    _lib.check(eng.lib.gmpc_bgemm_tn(eng.ctx, batch, M, N, K, C.c_void_p(Xd.data_ptr()),
+                                     C.c_void_p(Yd.data_ptr()), C.c_void_p(Cd.data_ptr()), 0.5, -2.0,
+                                     eng._stream()))
+    Yb = Y[:batch * K].reshape(batch, K, N).astype(np.float64)
+    ref = 0.5 * np.einsum("bkm,bkn->bmn", X.astype(np.float64), Yb) - 2.0 * C0
+    assert gu.rel_err(Cd.cpu().numpy(), ref) < 1e-5
