@@ -22,6 +22,12 @@ int gmpc_launch_linearize(int, int, int, int, const MlpDesc&, const uint32_t*, c
 int gmpc_launch_linearize_mfma(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
                                const int*, float*, int, int, hipStream_t);
 void gmpc_launch_bgemm_tn(const BgemmArgs&, hipStream_t);
+int gmpc_big_backward(const BigWork&, int, const MlpDesc&, const LinPad&, const uint32_t*, const float*,
+                      const float*, const float*, const float*, const float*, const float*, const int*,
+                      float*, float*, float*, float*, hipStream_t);
+void gmpc_launch_big_cont(int, int, int, const float*, const float*, const int*, const float*,
+                          const float*, const float*, const float*, const gmpc_ilqr_opts&, const int*,
+                          int*, hipStream_t);
 size_t gmpc_linpad_floats(const gmpc_shape*);
 void gmpc_linpad_prepare(const MlpDesc&, int, int, float*, size_t, LinPad*, hipStream_t);
 int gmpc_launch_terminal(int, int, int, const MlpDesc&, const float*, const float*, const int*,
@@ -79,11 +85,11 @@ static long mlp_count(int L, const int* dims) {
 static int check_shape(const gmpc_shape* s) {
   if (!s) return fail(GMPC_EINVAL, "shape is null");
   if (s->n < 1 || s->m < 1 || s->T < 1) return fail(GMPC_EINVAL, "n, m, T must be positive");
-  if (s->n > 64 || s->m > 32)
-    return fail(GMPC_EINVAL,
-                "unsupported shape n=%d m=%d: this build implements the small-state path "
-                "(n <= 64, m <= 32); the large-n Riccati path is not built yet", s->n, s->m);
-  if (GMPC_TB * s->m > GMPC_THREADS) return fail(GMPC_EINVAL, "m too large");
+  if (s->n > 1024 || s->m > 64)
+    return fail(GMPC_EINVAL, "unsupported shape n=%d m=%d: n <= 1024 and m <= 64 are built", s->n, s->m);
+  if (s->n <= 64 && s->m > 32)
+    return fail(GMPC_EINVAL, "unsupported shape n=%d m=%d: the small-state path needs m <= 32", s->n,
+                s->m);
   if (s->dyn_layers < 2 || s->dyn_layers > GMPC_MAX_LAYERS)
     return fail(GMPC_EINVAL, "dyn_layers must be in [2, %d]", GMPC_MAX_LAYERS);
   if (s->cost_layers < 1 || s->cost_layers > GMPC_MAX_LAYERS)
@@ -148,6 +154,9 @@ struct gmpc_ctx {
   // critic workspace
   float *critT, *gates, *cs, *hp, *hT, *dz, *hacts, *hdels, *dhT, *cscore, *closs;
   int hstride;
+  // large-state (n > 64) backward pass
+  bool big = false;
+  BigWork bw{};
   // shared scratch
   float *wpart, *scratch;
   long wpart_floats;
@@ -228,13 +237,34 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
   A_(maskc, B * T * Lh * GMPC_MW);
   A_(Xc, B * (T + 1) * n);
   A_(Uc, B * T * m);
-  A_(AB, B * T * n * nm);
+  c->big = s.n > 64;
+  if (!c->big) {
+    A_(AB, B * T * n * nm);
+  } else {
+    // step-major backward pass: one step's Jacobians and the n x n work matrices, each followed by
+    // zeroed rows the GEMMs may read past the end
+    c->bw.n = s.n; c->bw.m = s.m; c->bw.T = s.T;
+    const size_t pad = 16 * nm;
+#define B_(p, cnt) if (!rc) { rc = dalloc(c, &c->bw.p, (cnt)); if (!rc) (void)hipMemset(c->bw.p, 0, (cnt) * sizeof(float)); }
+    B_(ABt, B * n * nm + pad);
+    B_(P, B * n * n + pad);
+    B_(PA, B * n * n + pad);
+    B_(T1, B * n * n + pad);
+    B_(S, B * n * n + pad);
+    B_(PB, B * n * m + pad);
+    B_(Hm, B * m * n + pad);
+    B_(HGK, B * m * n + pad);
+    B_(Gr, B * m * m + pad);
+    B_(pvec, B * n); B_(lam, B * n); B_(sbuf, B); B_(gn2, B);
+#undef B_
+    c->AB = c->bw.ABt;
+  }
   A_(QT, B * n * n);
   A_(qT, B * n);
   A_(Xs, B * (T + 1) * n);
   A_(Us, B * T * m);
   A_(goals, B * (T + 1) * n);
-  A_(Ks, B * T * m * n);
+  A_(Ks, B * T * m * n + 16 * nm);
   A_(ks, B * T * m);
   A_(grads, B * T * m);
   A_(adjs, B * (T + 1) * n);
@@ -295,6 +325,7 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
     (void)hipMemset(c->hdels, 0, ((size_t)2 * B + 8) * c->hstride * sizeof(float));
     (void)hipMemset(c->hacts, 0, ((size_t)2 * B + 8) * c->hstride * sizeof(float));
   }
+  if (!rc) (void)hipMemset(c->Ks, 0, (B * T * m * n + 16 * nm) * sizeof(float));
   if (rc) {
     gmpc_destroy(c);
     return rc;
@@ -371,6 +402,27 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
                          const int* active, float* K, float* k, float* grad, float* adj, float* AB,
                          int* cont, const gmpc_ilqr_opts* opts, hipStream_t s) {
   const gmpc_shape& sh = c->sh;
+  if (c->big) {
+    // large state: terminal quadratisation, then the step-major MFMA pipeline (gmpc_large.hip)
+    if (gmpc_launch_terminal(B, sh.T, sh.n, c->cost, c->mpc_w, X, active, c->QT, c->qT, s) != 0)
+      return fail(GMPC_EINVAL, "terminal: unsupported fout");
+    HIP_TRY(hipGetLastError());
+    {
+      ProfScope ps(c, PROF_RICCATI, s);
+      // the gains feed the GEMMs as a padded operand: always build them in the ctx buffer
+      if (gmpc_big_backward(c->bw, B, c->dyn, c->lp, c->masks, X, U, goal, c->mpc_w, c->QT, c->qT, active,
+                            c->Ks, k, grad ? grad : c->grads, adj ? adj : c->adjs, s) != 0)
+        return fail(GMPC_EINVAL, "large-state backward: Jacobian kernel does not cover this shape");
+      if (K != c->Ks)
+        HIP_TRY(hipMemcpyAsync(K, c->Ks, (size_t)B * sh.T * sh.m * sh.n * sizeof(float),
+                               hipMemcpyDeviceToDevice, s));
+    }
+    if (cont)
+      gmpc_launch_big_cont(B, sh.T, sh.m, U, c->bw.gn2, c->iters, c->obj, c->alpha, c->obj_step,
+                           c->U_step, *opts, active, cont, s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   {
     ProfScope ps(c, PROF_LINEARIZE, s);
     // matrix-core chain; the VALU chain only serves shapes the MFMA tiling does not cover (or
@@ -416,6 +468,7 @@ extern "C" int gmpc_lqr_backward(gmpc_ctx* c, int B, const float* X, const float
   TRY(check_call(c, B));
   if (!X || !U || !goal) return fail(GMPC_EINVAL, "null argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c->big && AB) return fail(GMPC_EINVAL, "AB output is not materialised for n > 64 (pass NULL)");
   // relu masks at (X, U): recomputed so that any trajectory may be passed
   gmpc_launch_masks(B, c->sh.n, c->sh.m, c->sh.T, c->dyn, X, U, c->masks, s);
   return backward_pass(c, B, X, U, goal, nullptr, K ? K : c->Ks, k ? k : c->ks, grad, adjoints,
@@ -429,6 +482,7 @@ extern "C" int gmpc_lqr_backward_after_rollout(gmpc_ctx* c, int B, const float* 
                                                float* adjoints, float* AB, void* stream) {
   TRY(check_call(c, B));
   if (!X || !U || !goal) return fail(GMPC_EINVAL, "null argument");
+  if (c->big && AB) return fail(GMPC_EINVAL, "AB output is not materialised for n > 64 (pass NULL)");
   hipStream_t s = static_cast<hipStream_t>(stream);
   return backward_pass(c, B, X, U, goal, nullptr, K ? K : c->Ks, k ? k : c->ks, grad, adjoints,
                        AB ? AB : c->AB, nullptr, nullptr, s);
@@ -501,6 +555,9 @@ extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float*
 static int bind_critic(gmpc_ctx* c, const float* critic, CriticDesc& cd, hipStream_t s) {
   const gmpc_shape& sh = c->sh;
   if (sh.lstm_features <= 0) return fail(GMPC_EINVAL, "this ctx was created without a critic");
+  if (sh.n + sh.lstm_features > GMPC_THREADS)
+    return fail(GMPC_EINVAL, "the critic kernels need n + F <= %d (n = %d is not built yet)", GMPC_THREADS,
+                sh.n);
   const long n = sh.n, F = sh.lstm_features;
   cd.n = sh.n; cd.F = sh.lstm_features; cd.T1 = sh.T + 1;
   cd.Wcat = critic;
@@ -629,6 +686,7 @@ extern "C" int gmpc_bilevel_grad(gmpc_ctx* c, int B, int loss_kind, const float*
   TRY(check_call(c, B));
   if (c->solB != B) return fail(GMPC_EINVAL, "gmpc_ilqr_solve with B=%d must precede this call", B);
   if (!loss || !grad_sum) return fail(GMPC_EINVAL, "null argument");
+  if (c->big) return fail(GMPC_EINVAL, "the bilevel gradient for n > 64 is not built yet");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const gmpc_shape& sh = c->sh;
   const int n = sh.n, m = sh.m, T = sh.T;

@@ -207,6 +207,12 @@ struct BgemmArgs {
   const int* active;                    // [batch] or null
 };
 
+// workspace of the large-state backward pass (gmpc_large.hip)
+struct BigWork {
+  int n, m, T;
+  float *ABt, *P, *PA, *T1, *S, *PB, *Hm, *HGK, *Gr, *pvec, *lam, *sbuf, *gn2;
+};
+
 // zero-padded weight copies read by the MFMA Jacobian chain (gmpc_linearize_mfma.hip)
 struct LinPad {
   int NT, NTF, NGF;                     // column tiles: hidden GEMMs / input GEMM per group, groups

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bgemm_tn(BgemmArgs a) {
   const float* X = a.X + (size_t)b * a.sx;
   const float* Y = a.Y + (size_t)b * a.sy;
   float* C = a.C + (size_t)b * a.sc;
-  const int K = a.K, Kp = (K + 1) & ~1;
+  const int K = a.K, Kp = K & ~1;
   const int acol = mi * 32 + l31;
   const bool aok = acol < a.M;
   const float* ap = X + (aok ? acol : a.M - 1);
@@ -52,7 +52,18 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bgemm_tn(BgemmArgs a) {
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
   const float* bp0 = Y + (size_t)half * a.ldy + ng * 32 * NTW + l31;
-  gemm_tile<NTW>(bp0, a.ldy, Kp, afn, acc);
+  if (Kp > 0) gemm_tile<NTW>(bp0, a.ldy, Kp, afn, acc);
+  if (K & 1) {
+    // odd K: the last k-step pairs row K-1 with a zero row.  Row K of Y belongs to somebody else
+    // (the next batch element or time step) and may hold NaN, which 0 * x would let through.
+    const float av = half == 0 ? afn(K - 1) : 0.f;
+    const float* yr = Y + (size_t)(K - 1) * a.ldy + ng * 32 * NTW + l31;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const float bv = half == 0 ? yr[nt * 32] : 0.f;
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[nt], 0, 0, 0);
+    }
+  }
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
     const int col = ng * 32 * NTW + nt * 32 + l31;
@@ -85,4 +96,285 @@ void gmpc_launch_bgemm_tn(const BgemmArgs& a, hipStream_t s) {
     case 2: hipLaunchKernelGGL(k_bgemm_tn<2>, grid, blk, 0, s, a); break;
     default: hipLaunchKernelGGL(k_bgemm_tn<1>, grid, blk, 0, s, a); break;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-trajectory pieces of one backward step (everything that is not an n^3 product)
+// ------------------------------------------------------------------------------------------------
+struct BigStepArgs {
+  int B, n, m, T, t;
+  const float* X; const float* U; const float* goal; const float* mpc_w;
+  const float* ABt;      // [B][n][n+m]   Jacobians of step t
+  const float* Hm;       // [B][m][n]     B^T P A
+  const float* Gr;       // [B][m][m]     B^T P B
+  float* HGK;            // [B][m][n]     out: H + G K
+  float* pvec; float* lam;   // [B][n]    value vector / adjoint, updated in place
+  float* sbuf;           // [B]           out: sqrt(|x-g|^2 + alpha^2) of this step (for Q_t)
+  float* gn2;            // [B]           running sum of squared control gradients
+  const int* active;
+  float* K; float* k; float* grad; float* adj;   // [B][T][m][n], [B][T][m], [B][T][m], [B][T+1][n]
+};
+
+__global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = a.n, m = a.m, T = a.T, t = a.t, nm = n + m;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  float* G = reinterpret_cast<float*>(smem);     // m x m  (symmetrised R + B^T P B)
+  float* L = G + m * m;                          // m x m  Cholesky factor / work copy
+  float* pv = L + m * m;                         // n
+  float* lv = pv + n;                            // n
+  float* dv = lv + n;                            // n   x - goal
+  float* qv = dv + n;                            // n
+  float* pa = qv + n;                            // n   A^T p
+  float* uv = pa + n;                            // m
+  float* rv = uv + m;                            // m
+  float* hv = rv + m;                            // m
+  float* kv = hv + m;                            // m
+  float* red = kv + m;                           // 16
+  const float* AB = a.ABt + (size_t)b * n * nm;
+  const float* Hm = a.Hm + (size_t)b * m * n;
+  const size_t bt = (size_t)b * T + t;
+  const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]);
+  const float al = GMPC_ALPHA;
+  float dd = 0.f, uu = 0.f;
+  for (int i = tid; i < n; i += blockDim.x) {
+    const size_t xi = ((size_t)b * (T + 1) + t) * n + i;
+    const float d = a.X[xi] - a.goal[xi];
+    dv[i] = d;
+    dd = fmaf(d, d, dd);
+    pv[i] = a.pvec[(size_t)b * n + i];
+    lv[i] = a.lam[(size_t)b * n + i];
+  }
+  for (int j = tid; j < m; j += blockDim.x) {
+    const float u = a.U[bt * m + j];
+    uv[j] = u;
+    uu = fmaf(u, u, uu);
+  }
+  dd = wave_sum(dd); uu = wave_sum(uu);
+  if ((tid & 63) == 0) { red[tid >> 6] = dd; red[4 + (tid >> 6)] = uu; }
+  __syncthreads();
+  dd = (red[0] + red[1]) + (red[2] + red[3]);
+  uu = (red[4] + red[5]) + (red[6] + red[7]);
+  const float s = sqrtf(dd + al * al), su = sqrtf(uu + al * al);
+  const float isu = 1.f / su, isu3 = 1.f / (su * su * su);
+  if (tid == 0) a.sbuf[b] = s;
+  for (int i = tid; i < n; i += blockDim.x) qv[i] = w1 * dv[i] / s;
+  for (int j = tid; j < m; j += blockDim.x) rv[j] = w0 * uv[j] / su;
+  __syncthreads();
+  // g_t = r + B^T lam ; h = r + B^T p
+  for (int j = tid; j < m; j += blockDim.x) {
+    float g = 0.f, h = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float bij = AB[(size_t)i * nm + n + j];
+      g = fmaf(bij, lv[i], g);
+      h = fmaf(bij, pv[i], h);
+    }
+    g = rv[j] + g;
+    hv[j] = rv[j] + h;
+    a.grad[bt * m + j] = g;
+    kv[j] = g * g;     // staged for the gradient-norm sum
+  }
+  // lam_t = q + A^T lam ; pa = A^T p        (column c of A is read coalesced across threads)
+  for (int c = tid; c < n; c += blockDim.x) {
+    float vl = 0.f, vp = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float aic = AB[(size_t)i * nm + c];
+      vl = fmaf(aic, lv[i], vl);
+      vp = fmaf(aic, pv[i], vp);
+    }
+    pa[c] = vp;
+    const float ln = qv[c] + vl;
+    a.lam[(size_t)b * n + c] = ln;
+    a.adj[((size_t)b * (T + 1) + t) * n + c] = ln;
+  }
+  // G = sym(R + B^T P B)
+  const float* Gr = a.Gr + (size_t)b * m * m;
+  for (int e = tid; e < m * m; e += blockDim.x) {
+    const int i = e / m, j = e - i * m;
+    const float Rij = w0 * ((i == j ? isu : 0.f) - uv[i] * uv[j] * isu3);
+    L[e] = Rij + Gr[e];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float sg = 0.f;
+    for (int j = 0; j < m; ++j) sg += kv[j];
+    a.gn2[b] += sg;
+  }
+  for (int e = tid; e < m * m; e += blockDim.x) {
+    const int i = e / m, j = e - i * m;
+    G[e] = (L[e] + L[j * m + i]) * 0.5f;
+  }
+  __syncthreads();
+  // Cholesky of G + 1e-8 I in L (lower), column by column; NaN on a non-positive pivot
+  for (int e = tid; e < m * m; e += blockDim.x) L[e] = G[e] + ((e / m) == (e % m) ? 1e-8f : 0.f);
+  __syncthreads();
+  for (int j = 0; j < m; ++j) {
+    if (tid == 0) L[j * m + j] = sqrtf(L[j * m + j]);
+    __syncthreads();
+    const float d = L[j * m + j];
+    for (int i = j + 1 + tid; i < m; i += blockDim.x) L[i * m + j] /= d;
+    __syncthreads();
+    // trailing update of the lower triangle: L[i][k] -= L[i][j] L[k][j], j < k <= i
+    const int rem = m - j - 1;
+    for (int e = tid; e < rem * rem; e += blockDim.x) {
+      const int i = j + 1 + e / rem, k = j + 1 + e % rem;
+      if (k <= i) L[i * m + k] -= L[i * m + j] * L[k * m + j];
+    }
+    __syncthreads();
+  }
+  // [K k] = -(G + delta I)^-1 [H h], one right-hand-side column per thread (column n is h)
+  float* Kt = a.K + bt * m * n;
+  float* HGK = a.HGK + (size_t)b * m * n;
+  for (int c = tid; c <= n; c += blockDim.x) {
+    float y[64];                                   // m <= 64
+    for (int i = 0; i < m; ++i) {
+      float v = c < n ? Hm[(size_t)i * n + c] : hv[i];
+      for (int k = 0; k < i; ++k) v -= L[i * m + k] * y[k];
+      y[i] = v / L[i * m + i];
+    }
+    for (int i = m - 1; i >= 0; --i) {
+      float v = y[i];
+      for (int k = i + 1; k < m; ++k) v -= L[k * m + i] * y[k];
+      y[i] = v / L[i * m + i];
+    }
+    if (c < n) {
+      for (int i = 0; i < m; ++i) Kt[(size_t)i * n + c] = -y[i];
+      for (int i = 0; i < m; ++i) {
+        float v = 0.f;
+        for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], -y[k], v);
+        HGK[(size_t)i * n + c] = Hm[(size_t)i * n + c] + v;
+      }
+    } else {
+      for (int i = 0; i < m; ++i) { kv[i] = -y[i]; a.k[bt * m + i] = -y[i]; }
+    }
+  }
+  __syncthreads();
+  // p = q + A^T p + (H+GK)^T k + K^T h
+  for (int c = tid; c < n; c += blockDim.x) {
+    float v1 = 0.f, v2 = 0.f;
+    for (int i = 0; i < m; ++i) {
+      v1 = fmaf(HGK[(size_t)i * n + c], kv[i], v1);
+      v2 = fmaf(Kt[(size_t)i * n + c], hv[i], v2);
+    }
+    a.pvec[(size_t)b * n + c] = ((qv[c] + pa[c]) + v1) + v2;
+  }
+}
+
+// P = sym(Q_t + sym(T1) + S) = Q_t + (T1 + T1^T)/2 + (S + S^T)/2
+__global__ void k_big_pupdate(int B, int n, int T, int t, const float* X, const float* goal,
+                              const float* mpc_w, const float* sbuf, const float* T1, const float* S,
+                              const int* active, float* P) {
+  const int b = blockIdx.y;
+  if (active != nullptr && active[b] == 0) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n * n) return;
+  const int i = e / n, j = e - i * n;
+  const float w1 = sigmoidf_(mpc_w[1]);
+  const float s = sbuf[b];
+  const size_t xb = ((size_t)b * (T + 1) + t) * n;
+  const float di = X[xb + i] - goal[xb + i], dj = X[xb + j] - goal[xb + j];
+  const float Q = w1 * ((i == j ? 1.f / s : 0.f) - di * dj / (s * s * s));
+  const size_t o = (size_t)b * n * n;
+  const float t1 = (T1[o + e] + T1[o + (size_t)j * n + i]) * 0.5f;
+  const float ss = (S[o + e] + S[o + (size_t)j * n + i]) * 0.5f;
+  P[o + e] = (Q + t1) + ss;
+}
+
+__global__ void k_big_init(int B, int n, int T, const float* QT, const float* qT, const int* active,
+                           float* P, float* pvec, float* lam, float* adj, float* gn2) {
+  const int b = blockIdx.y;
+  if (active != nullptr && active[b] == 0) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n * n) P[(size_t)b * n * n + e] = QT[(size_t)b * n * n + e];
+  if (e < n) {
+    const float q = qT[(size_t)b * n + e];
+    pvec[(size_t)b * n + e] = q;
+    lam[(size_t)b * n + e] = q;
+    adj[((size_t)b * (T + 1) + T) * n + e] = q;
+  }
+  if (e == 0) gn2[b] = 0.f;
+}
+
+// trajax continuation test (same rule as the tail of k_riccati)
+__global__ void k_big_cont(int B, int T, int m, const float* U, const float* gn2, const int* iters,
+                           const float* obj, const float* alpha, const float* obj_step,
+                           const float* U_step, gmpc_ilqr_opts opts, const int* active, int* cont) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (active != nullptr && active[b] == 0) return;
+  float un2 = 0.f;
+  for (int e = 0; e < T * m; ++e) { const float u = U[(size_t)b * T * m + e]; un2 = fmaf(u, u, un2); }
+  float gn = sqrtf(gn2[b]);
+  if (isnan(gn)) gn = INFINITY;
+  const float aobj = fabsf(obj[b]) + 1.0f;
+  const float un = sqrtf(un2) + 1.0f;
+  const bool progressing = (obj_step[b] > opts.obj_step_threshold * aobj) &&
+                           (U_step[b] > opts.inputs_step_threshold * un);
+  const bool potential = (gn > opts.grad_norm_threshold) && (gn > opts.relative_grad_norm_threshold * aobj);
+  cont[b] = ((iters[b] < opts.maxiter) && progressing && potential && (alpha[b] > opts.alpha_min)) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host driver of one backward pass
+// ------------------------------------------------------------------------------------------------
+int gmpc_launch_linearize_mfma(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
+                               const uint32_t* masks, const int* active, float* AB, int samp_mul,
+                               int samp_add, hipStream_t s);
+
+int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad& lp,
+                      const uint32_t* masks, const float* X, const float* U, const float* goal,
+                      const float* mpc_w, const float* QT, const float* qT, const int* active, float* K,
+                      float* k, float* grad, float* adj, hipStream_t s) {
+  const int n = w.n, m = w.m, T = w.T, nm = n + m;
+  const dim3 ge((n * n + 255) / 256, B);
+  hipLaunchKernelGGL(k_big_init, ge, dim3(256), 0, s, B, n, T, QT, qT, active, w.P, w.pvec, w.lam, adj,
+                     w.gn2);
+  const size_t lds = ((size_t)2 * m * m + 5 * (size_t)n + 4 * (size_t)m + 16) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_step),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipGetLastError();
+    attr = true;
+  }
+  auto gemm = [&](int M, int N, int Kk, const float* Xp, long sx, int ldx, const float* Yp, long sy, int ldy,
+                  float* Cp, long sc, int ldc, float beta) {
+    BgemmArgs g;
+    g.batch = B; g.M = M; g.N = N; g.K = Kk;
+    g.X = Xp; g.sx = sx; g.ldx = ldx; g.Y = Yp; g.sy = sy; g.ldy = ldy; g.C = Cp; g.sc = sc; g.ldc = ldc;
+    g.alpha = 1.f; g.beta = beta; g.active = active;
+    gmpc_launch_bgemm_tn(g, s);
+  };
+  const long snn = (long)n * n, snm = (long)n * nm, smn = (long)m * n;
+  for (int t = T - 1; t >= 0; --t) {
+    if (gmpc_launch_linearize_mfma(B, T, n, m, dyn, lp, masks, active, w.ABt, T, t, s) != 0) return -1;
+    const float* A = w.ABt;
+    const float* Bm = w.ABt + n;
+    gemm(n, n, n, w.P, snn, n, A, snm, nm, w.PA, snn, n, 0.f);             // P A   (P symmetric)
+    gemm(n, m, n, w.P, snn, n, Bm, snm, nm, w.PB, (long)n * m, m, 0.f);    // P B
+    gemm(n, n, n, A, snm, nm, w.PA, snn, n, w.T1, snn, n, 0.f);            // A^T (P A)
+    gemm(m, n, n, Bm, snm, nm, w.PA, snn, n, w.Hm, smn, n, 0.f);           // B^T (P A)
+    gemm(m, m, n, Bm, snm, nm, w.PB, (long)n * m, m, w.Gr, (long)m * m, m, 0.f);   // B^T (P B)
+    BigStepArgs a;
+    a.B = B; a.n = n; a.m = m; a.T = T; a.t = t;
+    a.X = X; a.U = U; a.goal = goal; a.mpc_w = mpc_w; a.ABt = w.ABt; a.Hm = w.Hm; a.Gr = w.Gr;
+    a.HGK = w.HGK; a.pvec = w.pvec; a.lam = w.lam; a.sbuf = w.sbuf; a.gn2 = w.gn2; a.active = active;
+    a.K = K; a.k = k; a.grad = grad; a.adj = adj;
+    hipLaunchKernelGGL(k_big_step, dim3(B), dim3(GMPC_THREADS), lds, s, a);
+    const float* Kt = K + (size_t)t * m * n;          // K[b][t]: batch stride T*m*n
+    gemm(n, n, m, w.HGK, smn, n, Kt, (long)T * m * n, n, w.S, snn, n, 0.f);   // (H+GK)^T K
+    gemm(n, n, m, Kt, (long)T * m * n, n, w.Hm, smn, n, w.S, snn, n, 1.f);    // + K^T H
+    hipLaunchKernelGGL(k_big_pupdate, ge, dim3(256), 0, s, B, n, T, t, X, goal, mpc_w, w.sbuf, w.T1, w.S,
+                       active, w.P);
+  }
+  return 0;
+}
+
+void gmpc_launch_big_cont(int B, int T, int m, const float* U, const float* gn2, const int* iters,
+                          const float* obj, const float* alpha, const float* obj_step,
+                          const float* U_step, const gmpc_ilqr_opts& opts, const int* active, int* cont,
+                          hipStream_t s) {
+  hipLaunchKernelGGL(k_big_cont, dim3((B + 63) / 64), dim3(64), 0, s, B, T, m, U, gn2, iters, obj, alpha,
+                     obj_step, U_step, opts, active, cont);
 }

@@ -131,7 +131,9 @@ class Engine:
         n, m, T = self.n, self.m, self.T
         if out is None:
             out = dict(K=self.new(B, T, m, n), k=self.new(B, T, m), grad=self.new(B, T, m),
-                       adjoints=self.new(B, T + 1, n), AB=self.new(B, T, n, n + m))
+                       adjoints=self.new(B, T + 1, n))
+            if n <= 64:   # the large-state pass is step-major and never holds all T Jacobians
+                out["AB"] = self.new(B, T, n, n + m)
         fn = self.lib.gmpc_lqr_backward_after_rollout if after_rollout else self.lib.gmpc_lqr_backward
         _lib.check(fn(self.ctx, B, _ptr(X), _ptr(U), _ptr(goal), _ptr(out["K"]), _ptr(out["k"]),
                       _ptr(out["grad"]), _ptr(out["adjoints"]), _ptr(out.get("AB")), self._stream()))

@@ -56,7 +56,7 @@ def test_no_gpu_fails_loudly():
 
 def test_bad_shape_rejected_without_gpu_work():
     lib = _lib_or_skip()
-    s = make_shape(376, 17, 50, [393, 200, 376], [376, 128, 10])
+    s = make_shape(1100, 17, 50, [1117, 200, 1100], [1100, 128, 10])
     ctx = C.c_void_p()
     assert lib.gmpc_create(C.byref(s), 4, 0, C.byref(ctx)) == -1
     assert b"unsupported shape" in lib.gmpc_last_error()

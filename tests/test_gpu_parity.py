@@ -20,6 +20,9 @@ SHAPES = {
     "c2-cheetah": (17, 6, 50, 48, {}),
     "trained-like": (17, 6, 50, 32, dict(out_scale=0.1)),
     "wide": (40, 9, 6, 5, dict(dyn_hidden=(256, 64), cost_hidden=(256, 100), cost_fout=32)),
+    # n > 64: the step-major large-state backward pass (gmpc_large.hip)
+    "big-70": (70, 7, 6, 5, dict(dyn_hidden=(128, 96), cost_hidden=(64,), cost_fout=12, out_scale=0.3)),
+    "c4-humanoid": (376, 17, 4, 3, dict(out_scale=0.3)),
 }
 
 
@@ -79,11 +82,15 @@ def test_lqr_backward(name, after_rollout):
     bad_s[:, -1] |= gu.near_kink(pb64["cmlp"], X64[:, T])
     ok_b = ~bad_s.any(axis=1)
     assert ok_b.sum() >= B // 2, "too many trajectories near a relu kink; change the seed"
-    AB = out["AB"].cpu().numpy()
     AB32 = np.concatenate([lqr32[5][:, :T], lqr32[6][:, :T]], -1)
     AB64 = np.concatenate([lqr64[5][:, :T], lqr64[6][:, :T]], -1)
     ok_s = ~bad_s
-    gu.assert_parity("AB", AB[ok_s], AB32[ok_s], AB64[ok_s])
+    if n <= 64:
+        AB = out["AB"].cpu().numpy()
+        gu.assert_parity("AB", AB[ok_s], AB32[ok_s], AB64[ok_s])
+    else:   # step-major pass: only the Jacobians of the last processed step (t = 0) are left
+        AB = eng.debug_buffer(5, (B, n, n + m)).cpu().numpy()
+        gu.assert_parity("AB[t=0]", AB[ok_s[:, 0]], AB32[:, 0][ok_s[:, 0]], AB64[:, 0][ok_s[:, 0]])
     K32, k32, _, _ = orc.tvlqr(*lqr32)
     K64, k64, _, _ = orc.tvlqr(*lqr64)
     g32, a32 = orc.adjoint(lqr32[5], lqr32[6], lqr32[1], lqr32[3])
@@ -146,7 +153,7 @@ def test_adam_clip_step():
         gu.assert_parity(f"adam v step {step}", vd.cpu().numpy(), v, v64)
 
 
-@pytest.mark.parametrize("name", ["tiny-ragged", "trained-like"])
+@pytest.mark.parametrize("name", ["tiny-ragged", "trained-like", "big-70"])
 def test_ilqr_single_iteration_teacher_forced(name):
     """maxiter=1 from the same start: tvlqr + line search + re-linearisation, one iteration."""
     pb, pb64, eng = _setup(name)
@@ -261,7 +268,9 @@ def test_unsupported_shape_fails_loudly():
     from gan_mpc_amd import GmpcError
     from gan_mpc_amd.engine import Engine
     with pytest.raises(GmpcError, match="unsupported shape"):
-        Engine(376, 17, 50, [393, 200, 200, 200, 376], [376, 128, 128, 10], max_batch=4)
+        Engine(1100, 17, 5, [1117, 200, 200, 200, 1100], [1100, 128, 128, 10], max_batch=2)
+    with pytest.raises(GmpcError, match="unsupported shape"):
+        Engine(40, 40, 5, [80, 64, 40], [40, 32, 8], max_batch=2)
 
 
 def test_nan_trajectory_follows_the_trajax_rules_and_is_isolated():
