@@ -248,13 +248,10 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
 #define B_(p, cnt) if (!rc) { rc = dalloc(c, &c->bw.p, (cnt)); if (!rc) (void)hipMemset(c->bw.p, 0, (cnt) * sizeof(float)); }
     B_(ABt, B * n * nm + pad);
     B_(P, B * n * n + pad);
-    B_(PA, B * n * n + pad);
+    B_(PAB, B * n * nm + pad);
     B_(T1, B * n * n + pad);
-    B_(S, B * n * n + pad);
-    B_(PB, B * n * m + pad);
-    B_(Hm, B * m * n + pad);
-    B_(HGK, B * m * n + pad);
-    B_(Gr, B * m * m + pad);
+    B_(HG, B * m * nm + pad);
+    B_(W, B * m * n + pad);
     B_(pvec, B * n); B_(lam, B * n); B_(sbuf, B); B_(gn2, B);
 #undef B_
     c->AB = c->bw.ABt;

@@ -205,12 +205,16 @@ struct BgemmArgs {
   float* C; long sc; int ldc;           // C[b]: M x N
   float alpha, beta;
   const int* active;                    // [batch] or null
+  // optional second K-segment accumulated into the same product: C += X2^T Y2 (K2 rows)
+  const float* X2 = nullptr; long sx2 = 0; int ldx2 = 0;
+  const float* Y2 = nullptr; long sy2 = 0; int ldy2 = 0;
+  int K2 = 0;
 };
 
 // workspace of the large-state backward pass (gmpc_large.hip)
 struct BigWork {
   int n, m, T;
-  float *ABt, *P, *PA, *T1, *S, *PB, *Hm, *HGK, *Gr, *pvec, *lam, *sbuf, *gn2;
+  float *ABt, *P, *PAB, *T1, *HG, *W, *pvec, *lam, *sbuf, *gn2;
 };
 
 // zero-padded weight copies read by the MFMA Jacobian chain (gmpc_linearize_mfma.hip)

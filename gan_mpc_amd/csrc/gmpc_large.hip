@@ -5,10 +5,12 @@
 // per GPU at C4, 460 GB at C5).  The backward pass therefore runs STEP-MAJOR: for t = T-1 .. 0, for
 // the whole batch at once,
 //     [A_t | B_t]  <- MFMA Jacobian chain on the samples (b, t)          (k_linearize_mfma, strided)
-//     P A, P B, A^T(PA), B^T(PA), B^T(PB)  <- batched fp32-MFMA GEMMs    (k_bgemm_tn)
-//     gains, adjoint, value-vector update per trajectory                 (k_big_step)
-//     (H+GK)^T K + K^T H   <- batched GEMMs (K = m)                      (k_bgemm_tn)
-//     P <- sym(Q + sym(A^T P A) + ...)                                   (k_big_pupdate)
+//     [PA | PB] = P [A | B]                 batched fp32-MFMA GEMMs      (k_bgemm_tn_lds / k_bgemm_tn)
+//     [H | Gr]  = B^T [PA | PB]                                          (k_bgemm_tn)
+//     gains K_t k_t, adjoint, value vector, W = H + (H + G K)            (k_big_step)
+//     T1 = A^T (PA) + K^T W     one GEMM over two K-segments             (k_bgemm_tn_lds)
+//     P <- Q_t + sym(T1)                                                 (k_big_pupdate)
+// sym(K^T W) equals sym((H+GK)^T K + K^T H), the cross terms of trajax' lqr_step value update.
 // Every product is written as  C = sum_k X[k][:]^T Y[k][:]  ("TN") with row-major operands, so row k
 // of X / Y IS the MFMA A / B operand of k-step k and all global reads are coalesced; P's symmetry
 // turns P A into that form (X = P).  Reference arithmetic: trajax lqr_step / tvlqr / adjoint.
@@ -82,7 +84,143 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bgemm_tn(BgemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled variant for products whose M and N are both large: a workgroup of 4 waves (2 x 2) owns a
+// (64*WMT) x (64*WNT) block of C[b]; KC rows of X and Y at a time are staged through LDS (double
+// buffered, zero-filled past the matrix edges, so nothing is read out of bounds and a NaN in a
+// neighbouring matrix cannot leak in), each wave runs WMT x WNT MFMA tiles per k-step from it.
+// Against one-wave strips this cuts the L2 traffic per output ~3x, which is what bounded them.
+// A second K-segment (X2, Y2, K2) is accumulated into the same tile.
+// ------------------------------------------------------------------------------------------------
+template <int WMT, int WNT, int KC>
+__global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
+  constexpr int BM = 64 * WMT, BN = 64 * WNT;
+  constexpr int LX = KC * BM / GMPC_THREADS, LY = KC * BN / GMPC_THREADS;
+  __shared__ float Xs[2][KC][BM];
+  __shared__ float Ys[2][KC][BN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int mb = (a.M + BM - 1) / BM, nb = (a.N + BN - 1) / BN;
+  const long total = (long)a.batch * mb * nb;
+  // consecutive workgroup ids go round the 8 XCDs: give every XCD one contiguous range of blocks,
+  // so the blocks sharing a batch element's X / Y panels meet in the same L2
+  const long per = (total + 7) / 8;
+  const long item = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if ((long)(blockIdx.x >> 3) >= per || item >= total) return;
+  const int b = (int)(item / (mb * nb));
+  const int rem = (int)(item - (long)b * mb * nb);
+  const int mi = rem / nb, ni = rem - mi * nb;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  const int m0 = mi * BM, n0 = ni * BN;
+  f32x16 acc[WMT][WNT];
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) acc[i][j][rg] = 0.f;
+  float rx[LX], ry[LY];
+  const int c1 = (a.K + KC - 1) / KC, c2 = (a.K2 + KC - 1) / KC, nc = c1 + c2;
+  auto issue = [&](int ci) {
+    const bool first = ci < c1;
+    const float* X = first ? a.X + (size_t)b * a.sx : a.X2 + (size_t)b * a.sx2;
+    const float* Y = first ? a.Y + (size_t)b * a.sy : a.Y2 + (size_t)b * a.sy2;
+    const int ldx = first ? a.ldx : a.ldx2, ldy = first ? a.ldy : a.ldy2;
+    const int K = first ? a.K : a.K2, k0 = (first ? ci : ci - c1) * KC;
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+      const int e = tid + GMPC_THREADS * j, r = e / BM, c = e % BM;
+      const bool ok = (k0 + r < K) && (m0 + c < a.M);
+      rx[j] = ok ? X[(size_t)(k0 + r) * ldx + m0 + c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < LY; ++j) {
+      const int e = tid + GMPC_THREADS * j, r = e / BN, c = e % BN;
+      const bool ok = (k0 + r < K) && (n0 + c < a.N);
+      ry[j] = ok ? Y[(size_t)(k0 + r) * ldy + n0 + c] : 0.f;
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < LX; ++j) {
+      const int e = tid + GMPC_THREADS * j;
+      Xs[buf][e / BM][e % BM] = rx[j];
+    }
+#pragma unroll
+    for (int j = 0; j < LY; ++j) {
+      const int e = tid + GMPC_THREADS * j;
+      Ys[buf][e / BN][e % BN] = ry[j];
+    }
+  };
+  issue(0);
+  stage(0);
+  __syncthreads();
+  for (int ci = 0; ci < nc; ++ci) {
+    const int buf = ci & 1;
+    if (ci + 1 < nc) issue(ci + 1);
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 2) {
+      float av[WMT], bv[WNT];
+#pragma unroll
+      for (int i = 0; i < WMT; ++i) av[i] = Xs[buf][kk + half][(wm * WMT + i) * 32 + l31];
+#pragma unroll
+      for (int j = 0; j < WNT; ++j) bv[j] = Ys[buf][kk + half][(wn * WNT + j) * 32 + l31];
+#pragma unroll
+      for (int i = 0; i < WMT; ++i)
+#pragma unroll
+        for (int j = 0; j < WNT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (ci + 1 < nc) stage(buf ^ 1);
+    __syncthreads();
+  }
+  float* C = a.C + (size_t)b * a.sc;
+#pragma unroll
+  for (int i = 0; i < WMT; ++i)
+#pragma unroll
+    for (int j = 0; j < WNT; ++j) {
+      const int col = n0 + (wn * WNT + j) * 32 + l31;
+      if (col < a.N) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          const int row = m0 + (wm * WMT + i) * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+          if (row < a.M) {
+            float* cp = C + (size_t)row * a.ldc + col;
+            float v = a.alpha * acc[i][j][rg];
+            if (a.beta != 0.f) v = fmaf(a.beta, *cp, v);
+            *cp = v;
+          }
+        }
+      }
+    }
+}
+
+template <int WMT, int WNT>
+static void launch_lds(const BgemmArgs& a, hipStream_t s) {
+  constexpr int BM = 64 * WMT, BN = 64 * WNT;
+  const long total = (long)a.batch * ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  const long per = (total + 7) / 8;
+  hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT, 8>), dim3((unsigned)(per * 8)), dim3(GMPC_THREADS), 0, s, a);
+}
+
 void gmpc_launch_bgemm_tn(const BgemmArgs& a, hipStream_t s) {
+  if (a.M > 32 && a.N > 64) {
+    // column blocks of 128 / 192 / 256: the one that pads N least (ties: the widest)
+    int best = 2;
+    long waste = -1;
+    for (int w = 2; w <= 4; ++w) {
+      const long padded = (long)((a.N + 64 * w - 1) / (64 * w)) * 64 * w;
+      if (waste < 0 || padded <= waste) { waste = padded; best = w; }
+    }
+    switch (best) {
+      case 2: launch_lds<2, 2>(a, s); break;
+      case 3: launch_lds<2, 3>(a, s); break;
+      default: launch_lds<2, 4>(a, s); break;
+    }
+    return;
+  }
+  // a thin product: one wave per strip (the second K-segment is not supported here)
   const int tiles = (a.N + 31) / 32;
   const int ntw = tiles >= 8 && tiles % 8 == 0 ? 8 : tiles >= 6 && tiles % 6 == 0 ? 6
                   : tiles >= 4 ? 4 : tiles >= 2 ? 2 : 1;
@@ -105,15 +243,19 @@ struct BigStepArgs {
   int B, n, m, T, t;
   const float* X; const float* U; const float* goal; const float* mpc_w;
   const float* ABt;      // [B][n][n+m]   Jacobians of step t
-  const float* Hm;       // [B][m][n]     B^T P A
-  const float* Gr;       // [B][m][m]     B^T P B
-  float* HGK;            // [B][m][n]     out: H + G K
+  const float* HG;       // [B][m][n+m]   [B^T P A | B^T P B]
+  float* W;              // [B][m][n]     out: H + (H + G K)
   float* pvec; float* lam;   // [B][n]    value vector / adjoint, updated in place
   float* sbuf;           // [B]           out: sqrt(|x-g|^2 + alpha^2) of this step (for Q_t)
   float* gn2;            // [B]           running sum of squared control gradients
   const int* active;
   float* K; float* k; float* grad; float* adj;   // [B][T][m][n], [B][T][m], [B][T][m], [B][T+1][n]
 };
+
+static size_t big_step_lds(int n, int m) {
+  return ((size_t)2 * m * m + 5 * (size_t)n + 6 * (size_t)m + 16 + 2 * GMPC_THREADS +
+          (size_t)m * GMPC_THREADS) * sizeof(float);
+}
 
 __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -131,9 +273,13 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   float* rv = uv + m;                            // m
   float* hv = rv + m;                            // m
   float* kv = hv + m;                            // m
-  float* red = kv + m;                           // 16
+  float* gk = kv + m;                            // m   G k + h
+  float* gsq = gk + m;                           // m
+  float* red = gsq + m;                          // 16
+  float* part = red + 16;                        // 2 x 256 partial sums
+  float* ycol = part + 2 * GMPC_THREADS;         // m x 256: one solve column per thread
   const float* AB = a.ABt + (size_t)b * n * nm;
-  const float* Hm = a.Hm + (size_t)b * m * n;
+  const float* HG = a.HG + (size_t)b * m * nm;
   const size_t bt = (size_t)b * T + t;
   const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]);
   const float al = GMPC_ALPHA;
@@ -162,18 +308,28 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   for (int i = tid; i < n; i += blockDim.x) qv[i] = w1 * dv[i] / s;
   for (int j = tid; j < m; j += blockDim.x) rv[j] = w0 * uv[j] / su;
   __syncthreads();
-  // g_t = r + B^T lam ; h = r + B^T p
-  for (int j = tid; j < m; j += blockDim.x) {
+  // g_t = r + B^T lam ; h = r + B^T p : thread (rp, j) sums rows rp, rp + RP, ... of column j of B
+  {
+    const int MC = m <= 32 ? 32 : 64, RP = GMPC_THREADS / MC;
+    const int rp = tid / MC, j = tid - rp * MC;
     float g = 0.f, h = 0.f;
-    for (int i = 0; i < n; ++i) {
-      const float bij = AB[(size_t)i * nm + n + j];
-      g = fmaf(bij, lv[i], g);
-      h = fmaf(bij, pv[i], h);
+    if (j < m)
+      for (int i = rp; i < n; i += RP) {
+        const float bij = AB[(size_t)i * nm + n + j];
+        g = fmaf(bij, lv[i], g);
+        h = fmaf(bij, pv[i], h);
+      }
+    part[tid] = g;
+    part[GMPC_THREADS + tid] = h;
+    __syncthreads();
+    if (tid < m) {
+      float gs = 0.f, hs = 0.f;
+      for (int r = 0; r < RP; ++r) { gs += part[r * MC + tid]; hs += part[GMPC_THREADS + r * MC + tid]; }
+      gs = rv[tid] + gs;
+      hv[tid] = rv[tid] + hs;
+      a.grad[bt * m + tid] = gs;
+      gsq[tid] = gs * gs;
     }
-    g = rv[j] + g;
-    hv[j] = rv[j] + h;
-    a.grad[bt * m + j] = g;
-    kv[j] = g * g;     // staged for the gradient-norm sum
   }
   // lam_t = q + A^T lam ; pa = A^T p        (column c of A is read coalesced across threads)
   for (int c = tid; c < n; c += blockDim.x) {
@@ -189,16 +345,15 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     a.adj[((size_t)b * (T + 1) + t) * n + c] = ln;
   }
   // G = sym(R + B^T P B)
-  const float* Gr = a.Gr + (size_t)b * m * m;
   for (int e = tid; e < m * m; e += blockDim.x) {
     const int i = e / m, j = e - i * m;
     const float Rij = w0 * ((i == j ? isu : 0.f) - uv[i] * uv[j] * isu3);
-    L[e] = Rij + Gr[e];
+    L[e] = Rij + HG[(size_t)i * nm + n + j];
   }
   __syncthreads();
   if (tid == 0) {
     float sg = 0.f;
-    for (int j = 0; j < m; ++j) sg += kv[j];
+    for (int j = 0; j < m; ++j) sg += gsq[j];
     a.gn2[b] += sg;
   }
   for (int e = tid; e < m * m; e += blockDim.x) {
@@ -223,62 +378,98 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     }
     __syncthreads();
   }
-  // [K k] = -(G + delta I)^-1 [H h], one right-hand-side column per thread (column n is h)
+  // [K k] = -(G + delta I)^-1 [H h], one right-hand-side column per thread (column n is h); the
+  // thread keeps its column in LDS (ycol[i][tid]) and also emits W = H + (H + G K) for it
   float* Kt = a.K + bt * m * n;
-  float* HGK = a.HGK + (size_t)b * m * n;
+  float* W = a.W + (size_t)b * m * n;
+  float* y = ycol + tid;
   for (int c = tid; c <= n; c += blockDim.x) {
-    float y[64];                                   // m <= 64
     for (int i = 0; i < m; ++i) {
-      float v = c < n ? Hm[(size_t)i * n + c] : hv[i];
-      for (int k = 0; k < i; ++k) v -= L[i * m + k] * y[k];
-      y[i] = v / L[i * m + i];
+      float v = c < n ? HG[(size_t)i * nm + c] : hv[i];
+      for (int k = 0; k < i; ++k) v -= L[i * m + k] * y[k * GMPC_THREADS];
+      y[i * GMPC_THREADS] = v / L[i * m + i];
     }
     for (int i = m - 1; i >= 0; --i) {
-      float v = y[i];
-      for (int k = i + 1; k < m; ++k) v -= L[k * m + i] * y[k];
-      y[i] = v / L[i * m + i];
+      float v = y[i * GMPC_THREADS];
+      for (int k = i + 1; k < m; ++k) v -= L[k * m + i] * y[k * GMPC_THREADS];
+      y[i * GMPC_THREADS] = v / L[i * m + i];
     }
     if (c < n) {
-      for (int i = 0; i < m; ++i) Kt[(size_t)i * n + c] = -y[i];
+      for (int i = 0; i < m; ++i) Kt[(size_t)i * n + c] = -y[i * GMPC_THREADS];
       for (int i = 0; i < m; ++i) {
         float v = 0.f;
-        for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], -y[k], v);
-        HGK[(size_t)i * n + c] = Hm[(size_t)i * n + c] + v;
+        for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], -y[k * GMPC_THREADS], v);
+        const float hic = HG[(size_t)i * nm + c];
+        W[(size_t)i * n + c] = hic + (hic + v);
       }
     } else {
-      for (int i = 0; i < m; ++i) { kv[i] = -y[i]; a.k[bt * m + i] = -y[i]; }
+      for (int i = 0; i < m; ++i) { kv[i] = -y[i * GMPC_THREADS]; a.k[bt * m + i] = -y[i * GMPC_THREADS]; }
     }
   }
   __syncthreads();
-  // p = q + A^T p + (H+GK)^T k + K^T h
+  for (int i = tid; i < m; i += blockDim.x) {
+    float v = 0.f;
+    for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], kv[k], v);
+    gk[i] = v + hv[i];
+  }
+  __syncthreads();
+  // p = q + A^T p + H^T k + K^T (G k + h)      [= q + A^T p + (H+GK)^T k + K^T h, G symmetric]
   for (int c = tid; c < n; c += blockDim.x) {
     float v1 = 0.f, v2 = 0.f;
     for (int i = 0; i < m; ++i) {
-      v1 = fmaf(HGK[(size_t)i * n + c], kv[i], v1);
-      v2 = fmaf(Kt[(size_t)i * n + c], hv[i], v2);
+      v1 = fmaf(HG[(size_t)i * nm + c], kv[i], v1);
+      v2 = fmaf(Kt[(size_t)i * n + c], gk[i], v2);   // own column: written by this thread above
     }
     a.pvec[(size_t)b * n + c] = ((qv[c] + pa[c]) + v1) + v2;
   }
 }
 
-// P = sym(Q_t + sym(T1) + S) = Q_t + (T1 + T1^T)/2 + (S + S^T)/2
-__global__ void k_big_pupdate(int B, int n, int T, int t, const float* X, const float* goal,
-                              const float* mpc_w, const float* sbuf, const float* T1, const float* S,
-                              const int* active, float* P) {
-  const int b = blockIdx.y;
+// P = Q_t + (T1 + T1^T)/2 for the tile pair (I, J), (J, I): both tiles are read row-wise and meet
+// through LDS, so every global access is coalesced and P comes out exactly symmetric.
+__global__ __launch_bounds__(GMPC_THREADS) void k_big_pupdate(int n, int T, int t, const float* X,
+                                                              const float* goal, const float* mpc_w,
+                                                              const float* sbuf, const float* T1,
+                                                              const int* active, float* P) {
+  __shared__ float tA[32][33], tB[32][33], dI[32], dJ[32];
+  const int I = blockIdx.y, J = blockIdx.x, b = blockIdx.z;
+  if (I > J) return;
   if (active != nullptr && active[b] == 0) return;
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n * n) return;
-  const int i = e / n, j = e - i * n;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t o = (size_t)b * n * n;
+  const size_t xb = ((size_t)b * (T + 1) + t) * n;
+  if (threadIdx.x < 32) {
+    const int i = I * 32 + tx;
+    dI[tx] = i < n ? X[xb + i] - goal[xb + i] : 0.f;
+  } else if (threadIdx.x < 64) {
+    const int j = J * 32 + tx;
+    dJ[tx] = j < n ? X[xb + j] - goal[xb + j] : 0.f;
+  }
+  for (int r = ty; r < 32; r += 8) {
+    const int ia = I * 32 + r, ja = J * 32 + tx;
+    tA[r][tx] = (ia < n && ja < n) ? T1[o + (size_t)ia * n + ja] : 0.f;
+    const int ib = J * 32 + r, jb = I * 32 + tx;
+    tB[r][tx] = (ib < n && jb < n) ? T1[o + (size_t)ib * n + jb] : 0.f;
+  }
+  __syncthreads();
   const float w1 = sigmoidf_(mpc_w[1]);
   const float s = sbuf[b];
-  const size_t xb = ((size_t)b * (T + 1) + t) * n;
-  const float di = X[xb + i] - goal[xb + i], dj = X[xb + j] - goal[xb + j];
-  const float Q = w1 * ((i == j ? 1.f / s : 0.f) - di * dj / (s * s * s));
-  const size_t o = (size_t)b * n * n;
-  const float t1 = (T1[o + e] + T1[o + (size_t)j * n + i]) * 0.5f;
-  const float ss = (S[o + e] + S[o + (size_t)j * n + i]) * 0.5f;
-  P[o + e] = (Q + t1) + ss;
+  const float is = 1.f / s, is3 = 1.f / (s * s * s);
+  for (int r = ty; r < 32; r += 8) {
+    {
+      const int i = I * 32 + r, j = J * 32 + tx;
+      if (i < n && j < n) {
+        const float Q = w1 * ((i == j ? is : 0.f) - dI[r] * dJ[tx] * is3);
+        P[o + (size_t)i * n + j] = Q + (tA[r][tx] + tB[tx][r]) * 0.5f;
+      }
+    }
+    if (I != J) {
+      const int i = J * 32 + r, j = I * 32 + tx;
+      if (i < n && j < n) {
+        const float Q = w1 * (0.f - dI[tx] * dJ[r] * is3);
+        P[o + (size_t)i * n + j] = Q + (tA[tx][r] + tB[r][tx]) * 0.5f;
+      }
+    }
+  }
 }
 
 __global__ void k_big_init(int B, int n, int T, const float* QT, const float* qT, const int* active,
@@ -330,7 +521,8 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
   const dim3 ge((n * n + 255) / 256, B);
   hipLaunchKernelGGL(k_big_init, ge, dim3(256), 0, s, B, n, T, QT, qT, active, w.P, w.pvec, w.lam, adj,
                      w.gn2);
-  const size_t lds = ((size_t)2 * m * m + 5 * (size_t)n + 4 * (size_t)m + 16) * sizeof(float);
+  const size_t lds = big_step_lds(n, m);
+  if (lds > 128 * 1024) return -2;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_step),
@@ -338,35 +530,38 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
     (void)hipGetLastError();
     attr = true;
   }
+  const long snn = (long)n * n, snm = (long)n * nm, smn = (long)m * n, smnm = (long)m * nm;
   auto gemm = [&](int M, int N, int Kk, const float* Xp, long sx, int ldx, const float* Yp, long sy, int ldy,
-                  float* Cp, long sc, int ldc, float beta) {
+                  float* Cp, long sc, int ldc) {
     BgemmArgs g;
     g.batch = B; g.M = M; g.N = N; g.K = Kk;
     g.X = Xp; g.sx = sx; g.ldx = ldx; g.Y = Yp; g.sy = sy; g.ldy = ldy; g.C = Cp; g.sc = sc; g.ldc = ldc;
-    g.alpha = 1.f; g.beta = beta; g.active = active;
-    gmpc_launch_bgemm_tn(g, s);
+    g.alpha = 1.f; g.beta = 0.f; g.active = active;
+    return g;
   };
-  const long snn = (long)n * n, snm = (long)n * nm, smn = (long)m * n;
+  const int nt = (n + 31) / 32;
   for (int t = T - 1; t >= 0; --t) {
     if (gmpc_launch_linearize_mfma(B, T, n, m, dyn, lp, masks, active, w.ABt, T, t, s) != 0) return -1;
     const float* A = w.ABt;
     const float* Bm = w.ABt + n;
-    gemm(n, n, n, w.P, snn, n, A, snm, nm, w.PA, snn, n, 0.f);             // P A   (P symmetric)
-    gemm(n, m, n, w.P, snn, n, Bm, snm, nm, w.PB, (long)n * m, m, 0.f);    // P B
-    gemm(n, n, n, A, snm, nm, w.PA, snn, n, w.T1, snn, n, 0.f);            // A^T (P A)
-    gemm(m, n, n, Bm, snm, nm, w.PA, snn, n, w.Hm, smn, n, 0.f);           // B^T (P A)
-    gemm(m, m, n, Bm, snm, nm, w.PB, (long)n * m, m, w.Gr, (long)m * m, m, 0.f);   // B^T (P B)
+    // [PA | PB] = P [A | B]   (P symmetric, so P = P^T is the "TN" left operand)
+    gmpc_launch_bgemm_tn(gemm(n, n, n, w.P, snn, n, A, snm, nm, w.PAB, snm, nm), s);
+    gmpc_launch_bgemm_tn(gemm(n, m, n, w.P, snn, n, Bm, snm, nm, w.PAB + n, snm, nm), s);
+    // [H | Gr] = B^T [PA | PB]
+    gmpc_launch_bgemm_tn(gemm(m, nm, n, Bm, snm, nm, w.PAB, snm, nm, w.HG, smnm, nm), s);
     BigStepArgs a;
     a.B = B; a.n = n; a.m = m; a.T = T; a.t = t;
-    a.X = X; a.U = U; a.goal = goal; a.mpc_w = mpc_w; a.ABt = w.ABt; a.Hm = w.Hm; a.Gr = w.Gr;
-    a.HGK = w.HGK; a.pvec = w.pvec; a.lam = w.lam; a.sbuf = w.sbuf; a.gn2 = w.gn2; a.active = active;
+    a.X = X; a.U = U; a.goal = goal; a.mpc_w = mpc_w; a.ABt = w.ABt; a.HG = w.HG; a.W = w.W;
+    a.pvec = w.pvec; a.lam = w.lam; a.sbuf = w.sbuf; a.gn2 = w.gn2; a.active = active;
     a.K = K; a.k = k; a.grad = grad; a.adj = adj;
     hipLaunchKernelGGL(k_big_step, dim3(B), dim3(GMPC_THREADS), lds, s, a);
-    const float* Kt = K + (size_t)t * m * n;          // K[b][t]: batch stride T*m*n
-    gemm(n, n, m, w.HGK, smn, n, Kt, (long)T * m * n, n, w.S, snn, n, 0.f);   // (H+GK)^T K
-    gemm(n, n, m, Kt, (long)T * m * n, n, w.Hm, smn, n, w.S, snn, n, 1.f);    // + K^T H
-    hipLaunchKernelGGL(k_big_pupdate, ge, dim3(256), 0, s, B, n, T, t, X, goal, mpc_w, w.sbuf, w.T1, w.S,
-                       active, w.P);
+    // T1 = A^T (PA) + K_t^T W
+    BgemmArgs g = gemm(n, n, n, A, snm, nm, w.PAB, snm, nm, w.T1, snn, n);
+    g.X2 = K + (size_t)t * m * n; g.sx2 = (long)T * m * n; g.ldx2 = n;   // K[b][t]
+    g.Y2 = w.W; g.sy2 = smn; g.ldy2 = n; g.K2 = m;
+    gmpc_launch_bgemm_tn(g, s);
+    hipLaunchKernelGGL(k_big_pupdate, dim3(nt, nt, B), dim3(GMPC_THREADS), 0, s, n, T, t, X, goal, mpc_w,
+                       w.sbuf, w.T1, active, w.P);
   }
   return 0;
 }
