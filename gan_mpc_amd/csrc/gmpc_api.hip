@@ -36,7 +36,7 @@ void gmpc_launch_riccati(const RiccatiArgs&, hipStream_t);
 size_t gmpc_riccati_lds_bytes(int n, int m);
 void gmpc_launch_transpose(int, int, const float*, float*, hipStream_t);
 void gmpc_launch_lstm_fwd(int, const CriticDesc&, const float*, float*, float*, float*, float*,
-                          hipStream_t);
+                          const float*, hipStream_t);
 void gmpc_launch_head(int, const CriticDesc&, int, const float*, const float*, float*, float*,
                       float*, float*, float*, int, hipStream_t);
 void gmpc_launch_lstm_bwd(int, const CriticDesc&, const float*, const float*, const float*, float*,
@@ -157,6 +157,7 @@ struct gmpc_ctx {
   // large-state (n > 64) backward pass
   bool big = false;
   BigWork bw{};
+  float *WhT = nullptr, *xT = nullptr, *xproj = nullptr;   // wide-input critic (n + F > 256)
   // shared scratch
   float *wpart, *scratch;
   long wpart_floats;
@@ -297,6 +298,11 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
     A_(hp, Bc * T1 * F);
     A_(hT, Bc * F);
     A_(dz, (Bc * T1 + 8) * 4 * F);
+    if (n + F > GMPC_THREADS) {
+      A_(WhT, 4 * F * F);
+      A_(xT, Bc * T1 * n + 16 * Bc * T1);
+      A_(xproj, (Bc * T1 + 16) * 4 * F);
+    }
     A_(hacts, (Bc + 8) * c->hstride);
     A_(hdels, (Bc + 8) * c->hstride);
     A_(dhT, Bc * F);
@@ -552,9 +558,6 @@ extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float*
 static int bind_critic(gmpc_ctx* c, const float* critic, CriticDesc& cd, hipStream_t s) {
   const gmpc_shape& sh = c->sh;
   if (sh.lstm_features <= 0) return fail(GMPC_EINVAL, "this ctx was created without a critic");
-  if (sh.n + sh.lstm_features > GMPC_THREADS)
-    return fail(GMPC_EINVAL, "the critic kernels need n + F <= %d (n = %d is not built yet)", GMPC_THREADS,
-                sh.n);
   const long n = sh.n, F = sh.lstm_features;
   cd.n = sh.n; cd.F = sh.lstm_features; cd.T1 = sh.T + 1;
   cd.Wcat = critic;
@@ -574,9 +577,32 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
   TRY(bind_critic(c, critic, cd, s));
   const gmpc_shape& sh = c->sh;
   const int n = sh.n, F = sh.lstm_features, T1 = sh.T + 1;
+  // wide inputs (n + F > 256): x_t Wx for all steps is one MFMA GEMM up front and the LSTM kernels
+  // run on the recurrent half only (cr: n = 0, Wcat = Wh); dx comes back through a second GEMM
+  const bool widein = c->xT != nullptr;
+  const int R = Bc * T1, G4w = 4 * F;
+  CriticDesc cr = cd;
+  auto gemm1 = [&](int M, int N, int K, const float* X, int ldx, const float* Y, int ldy, float* Cp,
+                   int ldc) {
+    BgemmArgs g;
+    g.batch = 1; g.M = M; g.N = N; g.K = K;
+    g.X = X; g.sx = 0; g.ldx = ldx; g.Y = Y; g.sy = 0; g.ldy = ldy; g.C = Cp; g.sc = 0; g.ldc = ldc;
+    g.alpha = 1.f; g.beta = 0.f; g.active = nullptr;
+    gmpc_launch_bgemm_tn(g, s);
+  };
+  if (widein) {
+    cr.n = 0;
+    cr.Wcat = critic + (long)n * G4w;
+    cr.WcatT = c->WhT;
+    gmpc_launch_transpose(F, G4w, cr.Wcat, c->WhT, s);
+  }
   {
     ProfScope ps(c, PROF_LSTM_FWD, s);
-    gmpc_launch_lstm_fwd(Bc, cd, xseq, c->gates, c->cs, c->hp, c->hT, s);
+    if (widein) {
+      gmpc_launch_transpose(R, n, xseq, c->xT, s);                       // [R][n] -> [n][R]
+      gemm1(R, G4w, n, c->xT, R, critic, G4w, c->xproj, G4w);             // xproj = x Wx
+    }
+    gmpc_launch_lstm_fwd(Bc, cr, xseq, c->gates, c->cs, c->hp, c->hT, widein ? c->xproj : nullptr, s);
   }
   {
     ProfScope ps(c, PROF_HEAD, s);
@@ -585,7 +611,15 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
   }
   if (dxseq || want_wgrad) {
     ProfScope ps(c, PROF_LSTM_BWD, s);
-    gmpc_launch_lstm_bwd(Bc, cd, c->gates, c->cs, c->dhT, want_wgrad ? c->dz : nullptr, dxseq, s);
+    if (!widein) {
+      gmpc_launch_lstm_bwd(Bc, cd, c->gates, c->cs, c->dhT, want_wgrad ? c->dz : nullptr, dxseq, s);
+    } else {
+      gmpc_launch_lstm_bwd(Bc, cr, c->gates, c->cs, c->dhT, c->dz, nullptr, s);
+      if (dxseq) {
+        gmpc_launch_transpose(R, G4w, c->dz, c->xproj, s);               // dz^T: [4F][R]
+        gemm1(R, n, G4w, c->xproj, R, c->critT, n + F, dxseq, n);         // dx = dz Wx^T
+      }
+    }
   }
   if (want_wgrad) {
     ProfScope ps(c, PROF_WGRAD, s);

@@ -17,7 +17,7 @@
 template <int R4, int NXR>
 __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd, const float* xseq,
                                                            float* gates, float* cs, float* hp,
-                                                           float* hT, int stage_w) {
+                                                           float* hT, int stage_w, const float* xproj) {
   constexpr int SB = 4 * R4;
   constexpr int KC = NXR > 0 ? NXR + 64 : 1;
   float wreg[KC];
@@ -60,6 +60,19 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd
     float4 acc[R4];
 #pragma unroll
     for (int q = 0; q < R4; ++q) acc[q] = make_float4(bj, bj, bj, bj);
+    if (NXR == 0 && xproj != nullptr && tid < G4) {
+      // wide inputs: x_t Wx was formed by a GEMM beforehand (cd.n == 0 here, Wcat = Wh)
+#pragma unroll
+      for (int q = 0; q < R4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int sq = min(s0 + q * 4 + cc, Bc - 1);
+          v[cc] = xproj[((size_t)sq * T1 + t) * G4 + tid];
+        }
+        acc[q] = make_float4(bj + v[0], bj + v[1], bj + v[2], bj + v[3]);
+      }
+    }
     if (NXR > 0) {
 #pragma unroll
       for (int k = 0; k < KC; ++k)
@@ -481,7 +494,24 @@ __global__ void k_polyak(long count, const float* prev, const float* cur, float 
 // ---------------------------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------------------------
+// 32 x 32 tiles through LDS: both the read and the write are coalesced (large activations)
+__global__ __launch_bounds__(256) void k_transpose_tiled(int R, int C, const float* in, float* out) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int r = ty; r < 32; r += 8)
+    if (r0 + r < R && c0 + tx < C) tile[r][tx] = in[(size_t)(r0 + r) * C + c0 + tx];
+  __syncthreads();
+  for (int cc = ty; cc < 32; cc += 8)
+    if (c0 + cc < C && r0 + tx < R) out[(size_t)(c0 + cc) * R + r0 + tx] = tile[tx][cc];
+}
+
 void gmpc_launch_transpose(int R, int C, const float* in, float* out, hipStream_t s) {
+  if ((long)R * C > (1L << 16)) {
+    hipLaunchKernelGGL(k_transpose_tiled, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, s, R, C, in,
+                       out);
+    return;
+  }
   const int cnt = R * C;
   hipLaunchKernelGGL(k_transpose, dim3((cnt + 255) / 256), dim3(256), 0, s, R, C, in, out);
 }
@@ -489,7 +519,7 @@ void gmpc_launch_transpose(int R, int C, const float* in, float* out, hipStream_
 #define GMPC_CR4 1   // 4 sequences per workgroup
 
 void gmpc_launch_lstm_fwd(int Bc, const CriticDesc& cd, const float* xseq, float* gates, float* cs,
-                          float* hp, float* hT, hipStream_t s) {
+                          float* hp, float* hT, const float* xproj, hipStream_t s) {
   constexpr int R4 = GMPC_CR4;
   const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
   size_t lds = ((size_t)(cd.n + cd.F) + 4 * cd.F) * R4 * sizeof(float4);
@@ -506,13 +536,13 @@ void gmpc_launch_lstm_fwd(int Bc, const CriticDesc& cd, const float* xseq, float
   }
   if (cd.n == 17 && cd.F == 64)
     hipLaunchKernelGGL((k_lstm_fwd<R4, 17>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates,
-                       cs, hp, hT, 0);
+                       cs, hp, hT, 0, nullptr);
   else if (cd.n == 3 && cd.F == 64)
     hipLaunchKernelGGL((k_lstm_fwd<R4, 3>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates,
-                       cs, hp, hT, 0);
+                       cs, hp, hT, 0, nullptr);
   else
     hipLaunchKernelGGL((k_lstm_fwd<R4, 0>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates,
-                       cs, hp, hT, stage_w);
+                       cs, hp, hT, stage_w, xproj);
 }
 
 void gmpc_launch_head(int Bc, const CriticDesc& cd, int loss_kind, const float* hT,

@@ -102,7 +102,8 @@ def test_lqr_backward(name, after_rollout):
 
 
 @pytest.mark.parametrize("name,head", [("tiny-ragged", (12,)), ("c2-cheetah", ()),
-                                       ("c2-cheetah", (256, 256, 256))])
+                                       ("c2-cheetah", (256, 256, 256)), ("big-70", (32,)),
+                                       ("c4-humanoid", (256, 256, 256))])
 def test_critic_loss_grad(name, head):
     pb, pb64, eng = _setup(name, critic=True, head_hidden=head)
     d = eng.to_dev
@@ -120,8 +121,10 @@ def test_critic_loss_grad(name, head):
                      gu.pack_grads_critic(g64))
 
 
-def test_critic_score_vjp():
-    pb, pb64, eng = _setup("c2-cheetah", critic=True)
+@pytest.mark.parametrize("name", ["c2-cheetah", "c4-humanoid"])
+def test_critic_score_vjp(name):
+    """c4-humanoid: n + F > 256, the input projection and dx run as MFMA GEMMs around the LSTM."""
+    pb, pb64, eng = _setup(name, critic=True)
     d = eng.to_dev
     xs = pb["true_seq"]
     score, dx = eng.critic_score_vjp(d(xs), d(gu.critic_flat(pb)))
