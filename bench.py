@@ -30,6 +30,20 @@ WORKLOAD = dict(name="C3 synthetic HalfCheetah-shape n=17 m=6 H=50 B=1024/GPU, d
                 n=17, m=6, T=50, B=1024, dyn_hidden=(200, 200, 200), cost_hidden=(128, 128),
                 cost_fout=10, F=64, head_hidden=(256, 256, 256))
 
+# the other BASELINE.json configs, selectable for measurement (not the headline line): per-GPU shards
+# of C4 (Humanoid, batch 4096 over 8 GPUs) and C5 (synthetic n=1024, batch 8192 over 8 GPUs)
+WORKLOADS = {
+    "c3": WORKLOAD,
+    "c4": dict(name="C4 synthetic Humanoid-shape n=376 m=17 H=50 B=512/GPU (4096 over 8), dynamics MLP "
+                    "4x200, cost MLP 3x128->10, critic LSTM(64)+3x256 head",
+               n=376, m=17, T=50, B=512, dyn_hidden=(200, 200, 200), cost_hidden=(128, 128),
+               cost_fout=10, F=64, head_hidden=(256, 256, 256)),
+    "c5": dict(name="C5 synthetic n=1024 m=64 H=100 B=1024/GPU (8192 over 8), dynamics MLP 4x200, "
+                    "cost MLP 3x128->10, critic LSTM(64)+3x256 head",
+               n=1024, m=64, T=100, B=1024, dyn_hidden=(200, 200, 200), cost_hidden=(128, 128),
+               cost_fout=10, F=64, head_hidden=(256, 256, 256)),
+}
+
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 PEAK_HBM_GBS = 8000.0
 
@@ -39,6 +53,12 @@ def linearize_flops_per_sample(n, m, dyn_dims):
     products + first-layer product); SURVEY.md 8d 'Jacobian chain'."""
     hh = sum(a * b for a, b in zip(dyn_dims[1:-2], dyn_dims[2:-1]))
     return 2.0 * n * (hh + dyn_dims[1] * (n + m))
+
+
+def riccati_flops_per_sample(n, m):
+    """Dense products of one lqr_step (trajax tvlqr): P A, P B, A^T(PA), B^T(PA), B^T(PB) and the
+    cross terms K^T W; the m x m factorisation and the solves are lower order."""
+    return 2.0 * (2 * n ** 3 + 2 * n * n * m + n * m * m + n * n * m)
 
 
 def step_bytes_per_traj(n, m, T):
@@ -105,7 +125,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=WORKLOAD["B"], help="trajectories per GPU")
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS),
+                    help="c3 = the headline configuration; c4 / c5 = per-GPU shards of the large-state configs")
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (0: the workload's)")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,8 +162,8 @@ def main():
     from gan_mpc_amd import params as P
     from gan_mpc_amd.engine import Engine
 
-    w = dict(WORKLOAD)
-    B = args.batch
+    w = dict(WORKLOADS[args.workload])
+    B = args.batch or w["B"]
     n, m, T, F = w["n"], w["m"], w["T"], w["F"]
     pb = orc.make_problem(n, m, T, B, seed=1000 + rank, dyn_hidden=w["dyn_hidden"],
                           cost_hidden=w["cost_hidden"], cost_fout=w["cost_fout"], lstm_features=F,
@@ -217,10 +239,17 @@ def main():
         prof = eng.profile_read()
         eng.profile_enable(False)
         dom = max(prof, key=lambda kk: prof[kk][0])
-        ms, cnt = prof["linearize"]
-        flops = linearize_flops_per_sample(n, m, dyn_dims) * B * T
+        if n <= 64:
+            kname = "k_linearize"
+            ms, cnt = prof["linearize"]
+            flops = linearize_flops_per_sample(n, m, dyn_dims) * B * T
+        else:
+            # step-major large-state pass: Jacobian chain + batched GEMMs + gain kernels, timed as one
+            kname = "large-state backward (k_linearize_mfma + k_bgemm_tn_lds + k_big_step)"
+            ms, cnt = prof["riccati"]
+            flops = (linearize_flops_per_sample(n, m, dyn_dims) + riccati_flops_per_sample(n, m)) * B * T
         ach = flops / (ms / cnt * 1e-3) / 1e12
-        roof = {"kernel": "k_linearize", "bound": "mfma", "achieved": round(ach, 3),
+        roof = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3),
                 "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
                 "traffic": None,
                 "avg_launch_ms": round(ms / cnt, 4),
@@ -232,7 +261,7 @@ def main():
                              "peak_GBs": PEAK_HBM_GBS},
                 "kernel_ms_per_step": {kk: round(v[0] / nprof, 4) for kk, v in prof.items() if v[1]}}
         tr = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tr):
+        if os.path.exists(tr) and args.workload == "c3":
             try:
                 roof["traffic"] = json.load(open(tr)).get("k_linearize_hbm_bytes_per_launch")
             except Exception:
@@ -244,7 +273,9 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "trajectories/sec (rollout+backward+critic step) at batch=1024, H=50",
+            "metric": "trajectories/sec (rollout+backward+critic step) at batch=1024, H=50"
+                      if args.workload == "c3" else
+                      f"trajectories/sec (rollout+backward+critic step), workload {args.workload}",
             "value": round(value, 1), "unit": "trajectories/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

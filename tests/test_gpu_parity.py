@@ -23,6 +23,7 @@ SHAPES = {
     # n > 64: the step-major large-state backward pass (gmpc_large.hip)
     "big-70": (70, 7, 6, 5, dict(dyn_hidden=(128, 96), cost_hidden=(64,), cost_fout=12, out_scale=0.3)),
     "c4-humanoid": (376, 17, 4, 3, dict(out_scale=0.3)),
+    "c5-synthetic": (1024, 64, 3, 2, dict(out_scale=0.3)),
 }
 
 
