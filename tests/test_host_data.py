@@ -1,0 +1,179 @@
+"""Host-side data path: normalisers, history / replay buffers and the config loader
+against golden vectors produced by the REFERENCE's own modules (tests/golden/
+make_reference_fixtures.py), the trajectory loader against a loop-by-loop restatement of
+reference data_loader.py:68-129 (that module needs jax and cannot be imported)."""
+
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from gan_mpc_amd import data_buffers, data_loader, data_normalizer
+from gan_mpc_amd.config import load_config
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(GOLD, "reference_host_fixtures.npz"))
+
+
+def _joint(fx):
+    joint = data_normalizer.JointNormalizer(data_normalizer.StandardNormalizer(verbose=False),
+                                            data_normalizer.IdentityNormalizer())
+    joint.update(state_dataset=fx["states"], action_dataset=fx["actions"])
+    return joint
+
+
+def test_normalizers_match_reference_vectors(fx):
+    std = data_normalizer.StandardNormalizer(verbose=False)
+    std.update(fx["states"])
+    np.testing.assert_array_equal(std.mean, fx["std_mean"])
+    np.testing.assert_array_equal(std.std, fx["std_std"])
+    np.testing.assert_array_equal(std.normalize(fx["states"]), fx["std_normalized"])
+    ns, na = _joint(fx).normalize(fx["states"], fx["actions"])
+    np.testing.assert_array_equal(ns, fx["joint_states"])
+    np.testing.assert_array_equal(na, fx["joint_actions"])
+    np.testing.assert_array_equal(data_normalizer.IdentityNormalizer().normalize(fx["states"].tolist()),
+                                  fx["identity"])
+    with pytest.raises(NotImplementedError):
+        data_normalizer.BaseNormalizer().update(None)
+    back = data_normalizer.StandardNormalizer().load_state_dict(std.state_dict())
+    np.testing.assert_array_equal(back.normalize(fx["states"]), fx["std_normalized"])
+
+
+def test_history_buffer_matches_reference_vectors(fx):
+    buf = data_buffers.Buffer(maxlen=6, normalizer=_joint(fx))
+    xs, us = fx["buf_x_in"], fx["buf_u_in"]
+    for i in range(10):
+        buf.append_state(xs[i])
+        buf.append_action(us[i])
+    buf.append_state(xs[10])
+    np.testing.assert_array_equal(buf.get_state_data(), fx["buf_states"])
+    np.testing.assert_array_equal(buf.get_action_data(), fx["buf_actions"])
+    assert buf.get_state_data().shape == (7, 5) and buf.get_action_data().shape == (6, 2)
+    buf.clear()
+    assert buf.get_state_data().shape == (0,)
+
+
+def test_replay_buffer_matches_reference_vectors(fx):
+    rb = data_buffers.ReplayBuffer(horizon=7, q_maxlen=30, normalizer=_joint(fx))
+    for k in range(3):
+        rb.add(fx[f"rb_s{k}"], fx[f"rb_a{k}"])
+    s, a, nx = rb.get_dataset()
+    np.testing.assert_array_equal(s, fx["rb_states"])
+    np.testing.assert_array_equal(a, fx["rb_actions"])
+    np.testing.assert_array_equal(nx, fx["rb_next"])
+    assert s.shape == (30, 7, 5)            # 13 + 2 + 24 windows were added, the FIFO keeps the last 30
+    w = rb.from_traj_to_seq(fx["rb_s0"], fx["rb_a0"])
+    for got, key in zip(w, ("rb_win_states", "rb_win_actions", "rb_win_next")):
+        np.testing.assert_array_equal(got, fx[key])
+    # a trajectory no longer than the horizon contributes nothing (and does not raise)
+    e = rb.from_traj_to_seq(np.zeros((7, 5)), np.zeros((7, 2)))
+    assert all(x.shape == (0,) for x in e)
+    rb.clear()
+    assert rb.get_dataset()[0].shape == (0,)
+
+
+def test_config_matches_reference_vectors():
+    ref = json.load(open(os.path.join(GOLD, "reference_config_fixture.json")))
+    cfg = load_config.Config.from_yaml(os.path.join(GOLD, "mirror_config.yaml"))
+    assert cfg.to_dict() == ref["to_dict"]
+    assert cfg.mpc.horizon == ref["probe"]["mpc.horizon"]
+    assert cfg.mpc.model.cost.mlp.num_hidden_units == ref["probe"]["mpc.model.cost.mlp.num_hidden_units"]
+    again = load_config.Config.from_dict(cfg.to_dict())
+    assert again.to_dict() == ref["to_dict"]
+
+
+# ------------------------------------------------------------------------------------------------
+def _write_trajectories(tmp_path, rng, N=7, L=40, n=4, m=2):
+    rewards = rng.uniform(5.0, 25.0, (N, L))
+    rewards[1] *= 0.1                      # total < 500: must be dropped
+    rewards[4] *= 0.2
+    data = {"states": rng.normal(size=(N, L, n)).tolist(), "actions": rng.normal(size=(N, L, m)).tolist(),
+            "rewards": rewards.tolist(), "extra": [1, 2, 3]}
+    path = tmp_path / "trajectories.json"
+    path.write_text(json.dumps(data))
+    return str(path), data
+
+
+def _config(horizon=5, history=2, num_trajectories=4, trajectory_len=30):
+    return load_config.Config.from_dict({
+        "env": {"type": "dmcontrol", "expert": {"name": "cheetah_run"}},
+        "mpc": {"horizon": horizon, "history": history,
+                "train": {"num_trajectories": num_trajectories, "trajectory_len": trajectory_len}},
+        "expert_prediction": {"train": {"seqlen": 6}}})
+
+
+def _loader(tmp_path, rng, **kw):
+    path, data = _write_trajectories(tmp_path, rng)
+    norm = data_normalizer.JointNormalizer(data_normalizer.StandardNormalizer(verbose=False),
+                                           data_normalizer.IdentityNormalizer())
+    dl = data_loader.DataLoader(_config(**kw), norm)
+    with contextlib.redirect_stdout(io.StringIO()):
+        dl.init(path=path)
+    return dl, data
+
+
+def test_expert_trajectory_selection(tmp_path):
+    rng = np.random.default_rng(3)
+    dl, data = _loader(tmp_path, rng)
+    total = np.sum(data["rewards"], axis=1)
+    keep = [i for i in np.argsort(-total) if total[i] > 500][:4]
+    assert 1 not in keep and 4 not in keep
+    tr = dl.expert_trajectories
+    assert sorted(tr) == ["actions", "rewards", "states"]
+    np.testing.assert_array_equal(tr["states"], np.array(data["states"])[keep, :30])
+    np.testing.assert_array_equal(tr["rewards"], np.array(data["rewards"])[keep, :30])
+    # the normaliser saw exactly the selected data
+    np.testing.assert_allclose(dl.normalizer.state_normalizer.mean, tr["states"].mean((0, 1)))
+
+
+def test_cost_dataset_windows_follow_the_reference_loops(tmp_path):
+    rng = np.random.default_rng(4)
+    dl, _ = _loader(tmp_path, rng)
+    (Xtr, Ytr), (Xte, Yte) = dl.get_cost_dataset(key=11)
+    horizon, history = 5, 2
+    s_trajs = dl.normalizer.normalize_state(dl.expert_trajectories["states"])
+    X, Y = [], []
+    for s_traj in s_trajs:                               # reference data_loader.py:77-90, literally
+        traj_len, xsize = s_traj.shape
+        num_elems = traj_len - horizon
+        s_traj = np.concatenate([np.zeros((history, xsize)), s_traj], axis=0)
+        for i in range(history, num_elems):
+            X.append(s_traj[i - history: i + 1])
+            Y.append(s_traj[i: i + horizon + 1])
+    X, Y = np.array(X), np.array(Y)
+    perm = np.random.default_rng(11).permutation(len(X))
+    cut = int(len(X) * 0.8)
+    np.testing.assert_array_equal(Xtr, X[perm[:cut]])
+    np.testing.assert_array_equal(Ytr, Y[perm[:cut]])
+    np.testing.assert_array_equal(Xte, X[perm[cut:]])
+    np.testing.assert_array_equal(Yte, Y[perm[cut:]])
+    assert Xtr.shape[1:] == (history + 1, 4) and Ytr.shape[1:] == (horizon + 1, 4)
+    # the last history state of X is the first state of Y
+    np.testing.assert_array_equal(Xtr[:, -1], Ytr[:, 0])
+
+
+def test_expert_and_dynamics_datasets(tmp_path):
+    rng = np.random.default_rng(5)
+    dl, _ = _loader(tmp_path, rng)
+    (X, U, Y), (Xt, Ut, Yt) = dl.get_expert_dataset(key=2)
+    assert X.shape[1:] == (6, 4) and U.shape[1:] == (6, 2) and Y.shape == X.shape
+    assert len(X) + len(Xt) == 4 * (30 - 6)
+    np.testing.assert_array_equal(X[:, 1:], Y[:, :-1])          # next-state windows are shifted by one
+    Xd, Ud, Yd = dl.get_dynamics_dataset(key=2)                 # seqlen = horizon, train split only
+    assert Xd.shape[1:] == (5, 4) and len(Xd) == int(4 * (30 - 5) * 0.8)
+    np.testing.assert_array_equal(Xd[:, 1:], Yd[:, :-1])
+
+
+def test_loader_requires_init():
+    dl = data_loader.DataLoader(_config(), None)
+    with pytest.raises(Exception, match="call init"):
+        dl.get_cost_dataset(0)
+    with pytest.raises(Exception, match="call init"):
+        dl.get_expert_dataset(0)
