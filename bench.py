@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary-maxiter", type=int, default=10,
+                    help="maxiter of the secondary full-bilevel measurement (0: skip)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend: nccl (= RCCL over xGMI, the real thing) or gloo "
                          "(rehearsal of the multi-rank path on a box with fewer GPUs than ranks)")
@@ -267,6 +269,29 @@ def main():
             except Exception:
                 pass
 
+    # ---- secondary: full bilevel_optimization = iLQR solve at fixed maxiter + bilevel
+    # gradient (L2 upper loss), with the iteration histogram.  Not part of `value`.
+    secondary = None
+    if rank == 0 and world == 1 and args.secondary_maxiter > 0 and n <= 64:
+        kw = {"maxiter": args.secondary_maxiter}
+        desired = xseq[:B]
+        sol = eng.ilqr_solve(x0, U, goal, kw)           # warm-up
+        eng.bilevel_grad(B, 0, desired=desired)
+        torch.cuda.synchronize()
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            sol = eng.ilqr_solve(x0, U, goal, kw)
+            eng.bilevel_grad(B, 0, desired=desired)
+        torch.cuda.synchronize()
+        dt2 = (time.perf_counter() - t1) / reps
+        its = sol["iterations"].cpu().numpy()
+        hist = np.bincount(its, minlength=args.secondary_maxiter + 1)
+        secondary = {"what": f"gmpc_ilqr_solve(maxiter={args.secondary_maxiter}) + gmpc_bilevel_grad(L2) "
+                             f"on {B} trajectories",
+                     "trajectories_per_sec": round(B / dt2, 1), "ms": round(dt2 * 1e3, 3),
+                     "iteration_histogram": {str(i): int(c) for i, c in enumerate(hist) if c}}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, w)
@@ -282,7 +307,7 @@ def main():
             "config": {"workload": w["name"], "batch_per_gpu": B, "global_batch": B * world,
                        "horizon": T, "state_dim": n, "act_dim": m,
                        "parallelism": f"trajectory-sharded x{world}, 1 all-reduce of critic grads/step"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out))
     if world > 1:

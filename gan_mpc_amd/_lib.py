@@ -57,6 +57,7 @@ SIGNATURES = {
                                   _P, _P]),
     "gmpc_bilevel_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P]),
     "gmpc_upper_loss": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "gmpc_dynamics_loss_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_double, C.c_int, _P, _P, _P]),
     "gmpc_polyak": (C.c_int, [_P, C.c_long, _P, _P, C.c_double, _P, _P]),
     "gmpc_critic_loss_grad": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),
     "gmpc_critic_score_vjp": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P]),

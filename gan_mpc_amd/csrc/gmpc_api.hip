@@ -22,6 +22,9 @@ int gmpc_launch_linearize(int, int, int, int, const MlpDesc&, const uint32_t*, c
 int gmpc_launch_linearize_mfma(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
                                const int*, float*, int, int, hipStream_t);
 void gmpc_launch_bgemm_tn(const BgemmArgs&, hipStream_t);
+size_t gmpc_dynfit_stride(const gmpc_shape*);
+int gmpc_launch_dynfit(int, int, int, int, const MlpDesc&, const float*, const float*, const float*, float,
+                       int, float*, float*, float*, int, float*, hipStream_t);
 int gmpc_big_backward(const BigWork&, int, const MlpDesc&, const LinPad&, const uint32_t*, const float*,
                       const float*, const float*, const float*, const float*, const float*, const int*,
                       float*, float*, float*, float*, hipStream_t);
@@ -158,6 +161,9 @@ struct gmpc_ctx {
   bool big = false;
   BigWork bw{};
   float *WhT = nullptr, *xT = nullptr, *xproj = nullptr;   // wide-input critic (n + F > 256)
+  // dynamics regression (allocated on first use)
+  float *dfpred = nullptr, *dfacts = nullptr, *dfdels = nullptr, *dfloss = nullptr;
+  int dfstride = 0;
   // shared scratch
   float *wpart, *scratch;
   long wpart_floats;
@@ -696,6 +702,49 @@ extern "C" int gmpc_upper_loss(gmpc_ctx* c, int B, int loss_kind, const float* d
   if (c->solB != B) return fail(GMPC_EINVAL, "gmpc_ilqr_solve with B=%d must precede this call", B);
   if (!loss) return fail(GMPC_EINVAL, "null argument");
   TRY(upper_loss(c, B, loss_kind, desired, critic, loss, false, static_cast<hipStream_t>(stream)));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// dynamics regression (N3) ---------------------------------------------------------------------
+extern "C" int gmpc_dynamics_loss_grad(gmpc_ctx* c, int B, int S, const float* xseq, const float* useq,
+                                       const float* next_xseq, double discount, int teacher_forcing,
+                                       float* loss_sum, float* grad_sum, void* stream) {
+  TRY(check_call(c, B));
+  const gmpc_shape& sh = c->sh;
+  if (S < 1 || S > sh.T) return fail(GMPC_EINVAL, "S=%d outside [1, T=%d]", S, sh.T);
+  if (!xseq || !useq || !next_xseq || !loss_sum || !grad_sum) return fail(GMPC_EINVAL, "null argument");
+  if (sh.n + sh.m > GMPC_THREADS)
+    return fail(GMPC_EINVAL, "the dynamics regression kernel needs n + m <= %d", GMPC_THREADS);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!c->dfacts) {
+    const size_t rows = (size_t)c->maxB * sh.T;
+    c->dfstride = (int)gmpc_dynfit_stride(&sh);
+    int rc = dalloc(c, &c->dfpred, rows * sh.n);
+    if (!rc) rc = dalloc(c, &c->dfacts, (rows + 8) * c->dfstride);
+    if (!rc) rc = dalloc(c, &c->dfdels, (rows + 8) * c->dfstride);
+    if (!rc) rc = dalloc(c, &c->dfloss, c->maxB);
+    if (rc) return rc;
+    // operands of the MFMA weight-gradient GEMM are read a few rows past the end: keep them finite
+    HIP_TRY(hipMemsetAsync(c->dfacts, 0, (rows + 8) * c->dfstride * sizeof(float), s));
+    HIP_TRY(hipMemsetAsync(c->dfdels, 0, (rows + 8) * c->dfstride * sizeof(float), s));
+  }
+  if (gmpc_launch_dynfit(B, S, sh.n, sh.m, c->dyn, xseq, useq, next_xseq, (float)discount,
+                         teacher_forcing != 0, c->dfpred, c->dfacts, c->dfdels, c->dfstride, c->dfloss,
+                         s) != 0)
+    return fail(GMPC_EINVAL, "dynamics regression: unsupported layer width");
+  const int rows = B * S;
+  float* g = grad_sum;
+  int aoff = 0, doff = 0;
+  for (int l = 0; l < sh.dyn_layers; ++l) {
+    const int M = sh.dyn_dims[l], N = sh.dyn_dims[l + 1];
+    gmpc_launch_wgrad(rows, M, N, c->dfacts + aoff, c->dfstride, c->dfdels + doff, c->dfstride, g,
+                      g + (long)M * N, rows, c->wpart, 256, s, c->wpart_floats, true);
+    g += (long)M * N + N;
+    aoff += M;
+    doff += N;
+  }
+  gmpc_launch_sum(B, c->dfloss, loss_sum, 0, s);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,191 @@
+// Dynamics-model regression: batch of multi-step prediction losses and their weight
+// gradient.  Reference arithmetic: norm/dynamics_trainer.py:14-47 (predict_loss: scan over the
+// sequence, teacher forcing by jnp.where, residual MLP dynamics/nn.py:27-34), utils.py:230-240
+// (discounted_sum: the discount is built by repeated multiplication), :74-86 (batch mean).
+//
+// One workgroup of 256 threads owns 4 sequences (one float4 component each) for the forward sweep
+// and the BPTT sweep: thread j = neuron j of the current layer (widths <= 256), activations of the
+// current step in LDS, layer inputs / deltas of every (sequence, step) written to HBM as the row
+// operands of the weight-gradient GEMMs (k_wgrad_mfma, the same kernel the critic uses).
+#include "gmpc_device.h"
+
+struct DynFitArgs {
+  int B, S, n, m;
+  MlpDesc dyn;
+  const float* xseq;   // [B][S][n]
+  const float* useq;   // [B][S][m]
+  const float* yseq;   // [B][S][n]   next states
+  float gamma;
+  int teacher_forcing;
+  float* pred;         // [B][S][n]
+  float* acts;         // [B*S][stride]: a_0 | a_1 | ... | a_{L-1}   (layer inputs)
+  float* dels;         // [B*S][stride]: d_1 | ... | d_L             (layer output deltas)
+  int stride;
+  float* loss;         // [B]
+};
+
+__global__ __launch_bounds__(GMPC_THREADS) void k_dynfit(DynFitArgs a) {
+  constexpr int R4 = 1, SB = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* bufA = reinterpret_cast<float4*>(smem);          // [256] layer input
+  float4* bufB = bufA + GMPC_THREADS;                      // [256] layer output
+  float4* xin = bufB + GMPC_THREADS;                       // [n]   current input state
+  float4* lam = xin + GMPC_THREADS;                        // [n]   dL/d pred_t from the future
+  float* disc = reinterpret_cast<float*>(lam + GMPC_THREADS);   // [S]
+  float* red = disc + a.S;                                 // [4 * 4] loss partials per wave
+  const int tid = threadIdx.x;
+  const int n = a.n, m = a.m, S = a.S, L = a.dyn.L, nm = n + m;
+  const int s0 = blockIdx.x * SB;
+  float* xinf = reinterpret_cast<float*>(xin);
+  if (tid == 0) {
+    float d = 1.f;
+    for (int t = 0; t < S; ++t) { disc[t] = d; d *= a.gamma; }
+  }
+  __syncthreads();
+  float4 lacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---------------------------------------------------------------- forward sweep
+  for (int t = 0; t < S; ++t) {
+    if (t == 0 || a.teacher_forcing) {
+      for (int e = tid; e < n * SB; e += blockDim.x) {
+        const int sb = e / n, i = e - sb * n;
+        const int s = min(s0 + sb, a.B - 1);
+        xinf[i * SB + sb] = a.xseq[((size_t)s * S + t) * n + i];
+      }
+      __syncthreads();
+    }
+    float* af = reinterpret_cast<float*>(bufA);
+    for (int e = tid; e < nm * SB; e += blockDim.x) {
+      const int sb = e / nm, i = e - sb * nm;
+      const int s = min(s0 + sb, a.B - 1);
+      const float v = i < n ? xinf[i * SB + sb] : a.useq[((size_t)s * S + t) * m + (i - n)];
+      af[i * SB + sb] = v;
+      if (s0 + sb < a.B) a.acts[((size_t)s * S + t) * a.stride + i] = v;
+    }
+    __syncthreads();
+    float4* cur = bufA;
+    float4* nxt = bufB;
+    int fo = nm;                 // offset of a_{l+1} in the acts row
+    for (int l = 0; l < L; ++l) {
+      const int K = a.dyn.dims[l], N = a.dyn.dims[l + 1];
+      if (tid < N) {
+        const float bj = a.dyn.b[l][tid];
+        float4 acc[R4] = {make_float4(bj, bj, bj, bj)};
+        dense_rows<R4>(a.dyn.W[l], K, N, tid, cur, acc);
+        float4 v = acc[0];
+        if (l < L - 1) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+          nxt[tid] = v;
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc)
+            if (s0 + cc < a.B)
+              a.acts[((size_t)(s0 + cc) * S + t) * a.stride + fo + tid] = f4get(v, cc);
+        } else {
+          const float4 x = xin[tid];
+          v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+          float d[4];
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            const int s = min(s0 + cc, a.B - 1);
+            const size_t o = ((size_t)s * S + t) * n + tid;
+            d[cc] = f4get(v, cc) - a.yseq[o];
+            if (s0 + cc < a.B) a.pred[o] = f4get(v, cc);
+          }
+          const float w = disc[t];
+          lacc.x = fmaf(w * d[0], d[0], lacc.x);
+          lacc.y = fmaf(w * d[1], d[1], lacc.y);
+          lacc.z = fmaf(w * d[2], d[2], lacc.z);
+          lacc.w = fmaf(w * d[3], d[3], lacc.w);
+          xin[tid] = v;          // the next step's input when not teacher-forced (own element)
+        }
+      }
+      __syncthreads();
+      fo += N;
+      float4* tmp = cur; cur = nxt; nxt = tmp;
+    }
+  }
+  // per-sequence loss: waves, then the 4 wave partials in order
+  lacc.x = wave_sum(lacc.x); lacc.y = wave_sum(lacc.y); lacc.z = wave_sum(lacc.z); lacc.w = wave_sum(lacc.w);
+  if ((tid & 63) == 0) {
+    const int w = tid >> 6;
+    red[w * 4 + 0] = lacc.x; red[w * 4 + 1] = lacc.y; red[w * 4 + 2] = lacc.z; red[w * 4 + 3] = lacc.w;
+  }
+  for (int e = tid; e < n; e += blockDim.x) lam[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  if (tid < SB && s0 + tid < a.B)
+    a.loss[s0 + tid] = ((red[tid] + red[4 + tid]) + red[8 + tid]) + red[12 + tid];
+  // ---------------------------------------------------------------- BPTT sweep
+  // row layouts: a_l starts at aoff(l), d_{l+1} (the delta at the output of layer l) at doff(l)
+  auto aoff = [&](int l) { int o = l == 0 ? 0 : nm; for (int i = 1; i < l; ++i) o += a.dyn.dims[i]; return o; };
+  auto doff = [&](int l) { int o = 0; for (int i = 1; i <= l; ++i) o += a.dyn.dims[i]; return o; };
+  const int doff_last = doff(L - 1);
+  for (int t = S - 1; t >= 0; --t) {
+    float4 gsave = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < n) {
+      float g[4];
+      const float w2 = 2.f * disc[t];
+      const float4 lm = lam[tid];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) {
+        const int s = min(s0 + cc, a.B - 1);
+        const size_t o = ((size_t)s * S + t) * n + tid;
+        g[cc] = w2 * (a.pred[o] - a.yseq[o]) + f4get(lm, cc);
+        if (s0 + cc < a.B) a.dels[((size_t)s * S + t) * a.stride + doff_last + tid] = g[cc];
+      }
+      gsave = make_float4(g[0], g[1], g[2], g[3]);
+      bufA[tid] = gsave;
+    }
+    __syncthreads();
+    float4* cur = bufA;
+    float4* nxt = bufB;
+    for (int l = L - 1; l >= 1; --l) {
+      const int K = a.dyn.dims[l + 1], N = a.dyn.dims[l];      // d_l = relu'(a_l) . (W_l d_{l+1})
+      const int ao = aoff(l), dof = doff(l - 1);
+      if (tid < N) {
+        float4 acc[R4] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+        dense_rows<R4>(a.dyn.WT[l], K, N, tid, cur, acc);
+        float d[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const int s = min(s0 + cc, a.B - 1);
+          const size_t row = (size_t)s * S + t;
+          const float al = a.acts[row * a.stride + ao + tid];
+          d[cc] = al > 0.f ? f4get(acc[0], cc) : 0.f;
+          if (s0 + cc < a.B) a.dels[row * a.stride + dof + tid] = d[cc];
+        }
+        nxt[tid] = make_float4(d[0], d[1], d[2], d[3]);
+      }
+      __syncthreads();
+      float4* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (!a.teacher_forcing) {
+      if (tid < n) {
+        float4 acc[R4] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+        dense_rows<R4>(a.dyn.WT[0], a.dyn.dims[1], nm, tid, cur, acc);
+        lam[tid] = make_float4(acc[0].x + gsave.x, acc[0].y + gsave.y, acc[0].z + gsave.z,
+                               acc[0].w + gsave.w);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+size_t gmpc_dynfit_stride(const gmpc_shape* s) {
+  size_t in = 0, out = 0;
+  for (int l = 0; l < s->dyn_layers; ++l) { in += s->dyn_dims[l]; out += s->dyn_dims[l + 1]; }
+  return in > out ? in : out;
+}
+
+int gmpc_launch_dynfit(int B, int S, int n, int m, const MlpDesc& dyn, const float* xseq,
+                       const float* useq, const float* yseq, float gamma, int teacher_forcing,
+                       float* pred, float* acts, float* dels, int stride, float* loss, hipStream_t s) {
+  if (n + m > GMPC_THREADS) return -1;
+  for (int l = 0; l <= dyn.L; ++l)
+    if (dyn.dims[l] > GMPC_THREADS) return -1;
+  DynFitArgs a;
+  a.B = B; a.S = S; a.n = n; a.m = m; a.dyn = dyn;
+  a.xseq = xseq; a.useq = useq; a.yseq = yseq; a.gamma = gamma; a.teacher_forcing = teacher_forcing;
+  a.pred = pred; a.acts = acts; a.dels = dels; a.stride = stride; a.loss = loss;
+  const size_t lds = 4 * GMPC_THREADS * sizeof(float4) + ((size_t)S + 16) * sizeof(float);
+  hipLaunchKernelGGL(k_dynfit, dim3((B + 3) / 4), dim3(GMPC_THREADS), lds, s, a);
+  return 0;
+}

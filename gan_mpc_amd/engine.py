@@ -165,6 +165,16 @@ class Engine:
                                             _ptr(loss), self._stream()))
         return loss
 
+    def dynamics_loss_grad(self, xseq, useq, next_xseq, discount, teacher_forcing):
+        """-> (loss_sum[1], grad_sum[dyn_count]) of the multi-step prediction loss over the batch."""
+        B, S = xseq.shape[0], xseq.shape[1]
+        loss_sum = self.new(1)
+        grad_sum = self.new(self.dyn_count)
+        _lib.check(self.lib.gmpc_dynamics_loss_grad(
+            self.ctx, B, S, _ptr(xseq), _ptr(useq), _ptr(next_xseq), float(discount),
+            int(bool(teacher_forcing)), _ptr(loss_sum), _ptr(grad_sum), self._stream()))
+        return loss_sum, grad_sum
+
     def polyak(self, prev, cur, factor, out=None):
         out = cur if out is None else out
         _lib.check(self.lib.gmpc_polyak(self.ctx, prev.numel(), _ptr(prev), _ptr(cur), float(factor),

@@ -62,3 +62,97 @@ def get_critic_model(config):
     else:
         raise ValueError("Choose lstm model.")
     return critic_model.CriticModel(config, nn_model), model_config
+
+
+# ---- on-disk artefacts (reference utils.py:119-156) ---------------------------------------------
+import json  # noqa: E402
+import os  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+_MAIN_DIR_PATH = os.path.dirname(__file__)
+
+
+def _abs(path):
+    return path if os.path.isabs(path) else os.path.join(_MAIN_DIR_PATH, path)
+
+
+def check_or_create_dir(path):
+    if not os.path.exists(path):
+        os.makedirs(path, exist_ok=True)
+
+
+def save_json(data, dir_path, basename):
+    dir_path = _abs(dir_path)
+    check_or_create_dir(dir_path)
+    with open(os.path.join(dir_path, basename), "w") as fp:
+        json.dump(data, fp, indent=4, sort_keys=True)
+
+
+def load_json(path):
+    with open(_abs(path), "r") as fp:
+        return json.load(fp)
+
+
+def flatten_tree(tree, prefix=""):
+    """{'a': {'b': array}} -> {'a/b': array}; None leaves are dropped."""
+    out = {}
+    for k, v in tree.items():
+        name = f"{prefix}/{k}" if prefix else str(k)
+        if isinstance(v, dict):
+            out.update(flatten_tree(v, name))
+        elif v is not None:
+            out[name] = np.asarray(v)
+    return out
+
+
+def unflatten_tree(flat):
+    tree = {}
+    for name, v in flat.items():
+        node = tree
+        parts = name.split("/")
+        for p in parts[:-1]:
+            node = node.setdefault(p, {})
+        node[parts[-1]] = np.asarray(v)
+    return tree
+
+
+def save_all_args(dir_path, params, model_config, *other_json_args):
+    """reference utils.py:135-147: next numbered sub-directory with config.json, the parameters and
+    the loss curves.  Parameters are written as `params.npz` (one array per leaf, keys are the tree
+    paths) instead of a pickled dict, so loading them never executes code."""
+    abs_dir_path = _abs(dir_path)
+    check_or_create_dir(abs_dir_path)
+    runs = sorted((d for d in os.listdir(abs_dir_path) if d.isdigit()), key=lambda x: -int(x))
+    key = "0" if not runs else f"{int(runs[0]) + 1}"
+    full_path = os.path.join(abs_dir_path, key)
+    save_json(model_config, full_path, "config.json")
+    tree = params.to_tree() if hasattr(params, "to_tree") else params
+    np.savez(os.path.join(full_path, "params.npz"), **flatten_tree(tree))
+    for json_data, name in other_json_args:
+        save_json(json_data, full_path, name)
+    return full_path
+
+
+def load_params(params_path, from_np=True, allow_pickle=False):
+    """`params.npz` written by save_all_args, or the reference's pickled `params.npy`
+    (utils.py:150-156) when the caller opts in with allow_pickle=True (pickle runs code: only for
+    files you trust)."""
+    if not from_np:
+        raise NotImplementedError("params must be saved using numpy.")
+    path = _abs(params_path)
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            return unflatten_tree({k: z[k] for k in z.files})
+    if not allow_pickle:
+        raise ValueError(f"{path}: a pickled .npy parameter file needs allow_pickle=True")
+    return np.load(path, allow_pickle=True).item()
+
+
+def get_expert_model(config, x_size, u_size):
+    """reference utils.py:216-227 loads a pretrained behaviour-cloning sequence model; its
+    parameters ship with neither repository.  Until one is given, the goal is "hold
+    the current state" with zero initial controls."""
+    from gan_mpc_amd.expert import expert_model
+    del x_size
+    return expert_model.HoldExpert(config.mpc.horizon, u_size)

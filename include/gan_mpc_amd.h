@@ -158,6 +158,18 @@ int gmpc_adam_clip_step(gmpc_ctx* ctx, long count, float* params, const float* g
                         float* v, float grad_scale, int step, double lr, double max_norm, double b1,
                         double b2, double eps, void* stream);
 
+/* N3: dynamics-model regression, norm/dynamics_trainer.py:14-47 (predict_loss) and
+ * :62-86 (batch mean + value_and_grad) with utils.py:230-240 (discounted_sum).  For each of the B
+ * sequences: x_in_t = teacher_forcing ? xseq[t] : pred_{t-1} (x_in_0 = xseq[0]),
+ * pred_t = dynamics(x_in_t, useq[t]), loss = sum_t discount^t |pred_t - next_xseq[t]|^2.
+ *   xseq, next_xseq [B][S][n], useq [B][S][m], 1 <= S <= T, B <= max_batch
+ *   -> loss_sum [1] (sum over the batch), grad_sum [dynamics parameter count] in the flat flax
+ *      order of gmpc_set_params' dyn vector (sum over the batch: divide by the global batch size).
+ * Uses the dynamics parameters bound by gmpc_set_params.  Needs n + m <= 256. */
+int gmpc_dynamics_loss_grad(gmpc_ctx* ctx, int B, int S, const float* xseq, const float* useq,
+                            const float* next_xseq, double discount, int teacher_forcing,
+                            float* loss_sum, float* grad_sum, void* stream);
+
 /* Building block of the large-state (n > 64) Riccati path, exported for its unit test: batched
  * C[b] = alpha * X[b]^T Y[b] + beta * C[b] on the fp32 matrix cores; X[b] is K x M, Y[b] K x N,
  * C[b] M x N, row-major, densely packed per batch element; Y must be followed by >= 8 readable rows

@@ -771,6 +771,60 @@ def polyak(prev, new, factor):
 # --------------------------------------------------------------------------
 # synthetic problem generator shared by tests and bench
 # --------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------
+# N3: dynamics-model regression (reference norm/dynamics_trainer.py:14-90, utils.py:230-240)
+# ------------------------------------------------------------------------------------------------
+def dynamics_fit_loss_and_grad(dyn, xseq, useq, next_xseq, discount_factor, teacher_forcing):
+    """Batch mean of predict_loss and its gradient w.r.t. the dynamics MLP.
+
+    predict_loss (dynamics_trainer.py:14-47): x_in_t = teacher_forcing ? xseq[t] : pred_{t-1}
+    (x_in_0 = xseq[0]); pred_t = MLP([x_in_t, u_t]) + x_in_t; loss = sum_d sum_t g^t (pred_t -
+    next_x_t)^2 with the discount built by repeated multiplication (utils.discounted_sum).
+    train_per_update (:74-86) takes the mean over the minibatch.  Returns (loss, [(gW, gb), ...]).
+    """
+    dt = _dt(xseq, dyn[0][0])
+    B, S, n = xseq.shape
+    L = len(dyn)
+    disc = np.ones(S, dtype=dt)
+    g = dt.type(discount_factor)
+    for t in range(1, S):
+        disc[t] = disc[t - 1] * g
+    acts = []          # per step: inputs of every layer (a_0 .. a_{L-1})
+    preds = np.zeros((B, S, n), dtype=dt)
+    x_in = xseq[:, 0]
+    for t in range(S):
+        if teacher_forcing:
+            x_in = xseq[:, t]
+        a = np.concatenate([x_in, useq[:, t]], axis=-1)
+        layer_in = []
+        for l, (W, b) in enumerate(dyn):
+            layer_in.append(a)
+            a = a @ W + b
+            if l < L - 1:
+                a = np.maximum(a, 0)
+        pred = a + x_in
+        preds[:, t] = pred
+        acts.append(layer_in)
+        x_in = pred
+    diff = preds - next_xseq
+    loss = (disc[None, :, None] * diff * diff).sum(axis=(1, 2))
+    grads = [(np.zeros_like(W), np.zeros_like(b)) for W, b in dyn]
+    lam = np.zeros((B, n), dtype=dt)
+    for t in range(S - 1, -1, -1):
+        gout = dt.type(2.0) * disc[t] * diff[:, t] + lam
+        d = gout
+        for l in range(L - 1, -1, -1):
+            a_l = acts[t][l]
+            grads[l][0][...] += a_l.T @ d
+            grads[l][1][...] += d.sum(axis=0)
+            d = d @ dyn[l][0].T
+            if l > 0:
+                d = d * (a_l > 0)
+        lam = np.zeros((B, n), dtype=dt) if teacher_forcing else d[:, :n] + gout
+    inv = dt.type(1.0) / dt.type(B)
+    return loss.mean(), [(gW * inv, gb * inv) for gW, gb in grads]
+
+
 def lecun_normal(rng, fan_in, fan_out, dtype):
     return (rng.standard_normal((fan_in, fan_out)) / np.sqrt(fan_in)).astype(dtype)
 

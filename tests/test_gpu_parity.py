@@ -337,3 +337,31 @@ def test_bgemm_tn_matches_float64(M, N, K, batch):
     Yb = Y[:batch * K].reshape(batch, K, N).astype(np.float64)
     ref = 0.5 * np.einsum("bkm,bkn->bmn", X.astype(np.float64), Yb) - 2.0 * C0
     assert gu.rel_err(Cd.cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("name,tf,S", [("tiny-ragged", True, 8), ("tiny-ragged", False, 5),
+                                       ("trained-like", True, 50), ("trained-like", False, 50),
+                                       ("wide", False, 6)])
+def test_dynamics_loss_grad(name, tf, S):
+    """N3: batch of multi-step prediction losses + weight gradient (dynamics_trainer.py:14-86)."""
+    pb, pb64, eng = _setup(name)
+    d = eng.to_dev
+    B, n, m = pb["B"], pb["n"], pb["m"]
+    rng = np.random.default_rng(21)
+    xseq = rng.standard_normal((B, S, n)).astype(np.float32)
+    useq = np.tanh(rng.standard_normal((B, S, m))).astype(np.float32)
+    yseq = rng.standard_normal((B, S, n)).astype(np.float32)
+    gamma = 0.95
+    ls, gs = eng.dynamics_loss_grad(d(xseq), d(useq), d(yseq), gamma, tf)
+    l32, g32 = orc.dynamics_fit_loss_and_grad(pb["dyn"], xseq, useq, yseq, gamma, tf)
+    l64, g64 = orc.dynamics_fit_loss_and_grad(pb64["dyn"], xseq.astype(np.float64),
+                                              useq.astype(np.float64), yseq.astype(np.float64),
+                                              gamma, tf)
+    flat = lambda g: np.concatenate([t.ravel() for Wb in g for t in Wb])
+    gu.assert_parity("dynamics loss", ls.cpu().numpy()[0] / B, l32, l64)
+    gu.assert_parity("dynamics grad", gs.cpu().numpy() / B, flat(g32), flat(g64), tol=1e-5)
+    from gan_mpc_amd import GmpcError
+    with pytest.raises(GmpcError, match="outside"):
+        eng.dynamics_loss_grad(d(np.zeros((B, pb["T"] + 1, n), np.float32)),
+                               d(np.zeros((B, pb["T"] + 1, m), np.float32)),
+                               d(np.zeros((B, pb["T"] + 1, n), np.float32)), gamma, tf)

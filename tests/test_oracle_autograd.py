@@ -213,3 +213,41 @@ def test_kat_cholesky_nan_on_indefinite():
     np.testing.assert_allclose(L @ np.swapaxes(L, -1, -2), G, rtol=1e-14)
     x = orc.cho_solve(L, np.array([[[1.0], [2.0]]]))
     np.testing.assert_allclose(G @ x, [[[1.0], [2.0]]], rtol=1e-13)
+
+
+@pytest.mark.parametrize("teacher_forcing", [True, False])
+def test_dynamics_fit_gradient_matches_autograd(teacher_forcing):
+    """N3: batch-mean predict_loss (dynamics_trainer.py:14-47) and its weight gradient."""
+    import torch
+    rng = np.random.default_rng(8)
+    n, m, S, B = 4, 2, 6, 5
+    dyn = orc.make_mlp(rng, [n + m, 9, 7, n], np.float64, bias_scale=0.3)
+    xseq = rng.standard_normal((B, S, n))
+    useq = rng.standard_normal((B, S, m))
+    yseq = rng.standard_normal((B, S, n))
+    gamma = 0.9
+    loss, grads = orc.dynamics_fit_loss_and_grad(dyn, xseq, useq, yseq, gamma, teacher_forcing)
+    Ws = [(torch.tensor(W, requires_grad=True), torch.tensor(b, requires_grad=True)) for W, b in dyn]
+    X, U, Y = map(torch.tensor, (xseq, useq, yseq))
+    total = 0.0
+    for bi in range(B):
+        xprev = X[bi, 0]
+        acc = torch.zeros(n, dtype=torch.float64)
+        disc = 1.0
+        for t in range(S):                                   # the scan body, literally
+            x = X[bi, t] if teacher_forcing else xprev
+            q = torch.cat([x, U[bi, t]])
+            for l, (W, b) in enumerate(Ws):
+                q = q @ W + b
+                if l < len(Ws) - 1:
+                    q = torch.relu(q)
+            xprev = q + x
+            acc = acc + disc * (xprev - Y[bi, t]) ** 2       # utils.discounted_sum
+            disc *= gamma
+        total = total + acc.sum()
+    total = total / B
+    total.backward()
+    assert abs(loss - float(total)) < 1e-12 * abs(float(total))
+    for (gW, gb), (W, b) in zip(grads, Ws):
+        np.testing.assert_allclose(gW, W.grad.numpy(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(gb, b.grad.numpy(), rtol=1e-10, atol=1e-12)
