@@ -1,0 +1,154 @@
+"""Dynamics-model training (reference norm/dynamics_trainer.py:14-194): multi-step prediction
+regression with teacher forcing on the expert windows, then on windows replayed from the policy's
+own rollouts in the environment.
+
+The loss and its gradient are one fused GPU call (gmpc_dynamics_loss_grad); minibatch sampling,
+the teacher-forcing schedule and the environment loop are host code with the reference's names.
+`key` is a NumPy seed / Generator; `env` is any object with the dm_control protocol (reset() / step(u)
+-> timestep with .observation (dict), .reward, .last()); with env=None only the offline part runs."""
+
+import numpy as np
+import torch
+
+from gan_mpc_amd import parallel, utils
+
+
+def _rng(key):
+    return key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+
+
+def _loss_and_grad(policy, dparams, X, U, Y, discount_factor, teacher_forcing):
+    """(mean loss, mean gradient over the global batch) for this rank's shard X, U, Y."""
+    B = X.shape[0]
+    eng = policy.bind(dparams, B)          # refreshes the transposed weight copies
+    d = eng.to_dev
+    ls, gs = eng.dynamics_loss_grad(d(X), d(U), d(Y), discount_factor, teacher_forcing)
+    packed = torch.cat([ls, gs])
+    parallel.allreduce_mean_from_sums(packed, B)
+    return packed[0], packed[1:]
+
+
+def predict_loss(policy, params, xseq, useq, next_xseq, discount_factor, teacher_forcing):
+    """reference dynamics_trainer.py:14-47, one sequence (seqlen, xsize) -> scalar."""
+    dparams = policy.to_device_params(params)
+    loss, _ = _loss_and_grad(policy, dparams, np.asarray(xseq, np.float32)[None],
+                             np.asarray(useq, np.float32)[None],
+                             np.asarray(next_xseq, np.float32)[None], discount_factor,
+                             teacher_forcing)
+    return loss
+
+
+def train_per_update(train_args, opt_state, params, perm, dataset, discount_factor, teacher_forcing):
+    """reference :50-90: scan over the minibatches of `perm`: mean loss -> grads -> clip+Adam."""
+    policy, opt = train_args
+    X, U, Y = dataset
+    losses = []
+    for p in perm:
+        lo, hi = parallel.shard_range(len(p))
+        ps = p[lo:hi]
+        loss, grads = _loss_and_grad(policy, params, X[ps], U[ps], Y[ps], discount_factor,
+                                     teacher_forcing)
+        params, opt_state = opt.update(policy._engine, params, grads, opt_state)
+        losses.append(loss)
+    return params, opt_state, sum(float(l) for l in losses) / len(losses)
+
+
+def train_params(train_args, opt_state, params, dataset, num_updates, batch_size, discount_factor,
+                 teacher_forcing_factor, key, id):
+    """reference :93-124"""
+    policy, _ = train_args
+    rng = _rng(key)
+    params = policy.to_device_params(params)
+    dataset = tuple(np.asarray(d, np.float32) for d in dataset)
+    datasize = dataset[0].shape[0]
+    steps_per_update = datasize // batch_size
+    train_losses = []
+    if steps_per_update == 0:
+        return params, opt_state, train_losses
+    for up in range(1, num_updates + 1):
+        perm = rng.choice(datasize, size=(steps_per_update, batch_size))
+        teacher_forcing = (id + up) <= (num_updates * teacher_forcing_factor)
+        params, opt_state, train_loss = train_per_update(
+            train_args=train_args, opt_state=opt_state, params=params, perm=perm, dataset=dataset,
+            discount_factor=discount_factor, teacher_forcing=teacher_forcing)
+        train_losses.append(float(train_loss))
+    return params, opt_state, train_losses
+
+
+@utils.timeit
+def train(env, train_args, opt_state, params, dataset, buffers, num_episodes,
+          max_interactions_per_episode, num_updates, batch_size, discount_factor,
+          teacher_forcing_factor, key, id):
+    """reference :127-194"""
+    train_policy, eval_policy, opt = train_args
+    replay_buffer, buffer = buffers
+    rng = _rng(key)
+    params = train_policy.to_device_params(params)
+
+    if id == 1:       # warm start on the expert windows, fully teacher-forced
+        params, opt_state, _ = train_params(
+            train_args=(train_policy, opt), opt_state=opt_state, params=params, dataset=dataset,
+            num_updates=3, batch_size=batch_size, discount_factor=discount_factor,
+            teacher_forcing_factor=1.0, key=rng, id=0)
+
+    episode_rewards, episode_train_losses, episode_test_losses = [], [], []
+    for ep in range(1, (num_episodes if env is not None else 0) + 1):
+        state_traj, action_traj, _, rewards = run_dm_policy(
+            env=env, policy_fn=eval_policy.get_optimal_action, params=params, buffer=buffer,
+            max_interactions=max_interactions_per_episode)
+        replay_buffer.add(state_traj, action_traj)
+        episode_rewards.append(rewards)
+        params, opt_state, train_losses = train_params(
+            train_args=(train_policy, opt), opt_state=opt_state, params=params,
+            dataset=replay_buffer.get_dataset(), num_updates=num_updates, batch_size=batch_size,
+            discount_factor=discount_factor,
+            teacher_forcing_factor=teacher_forcing_factor * num_episodes, key=rng,
+            id=(num_updates * (ep - 1)))
+        episode_train_losses.extend(train_losses)
+    return (params, opt_state, (replay_buffer, buffer), episode_rewards, episode_train_losses,
+            episode_test_losses)
+
+
+# ---- environment loop (reference utils.py:101-107, 257-308) -------------------------------------
+def flatten_tree_obs(obs):
+    return np.concatenate([np.array([v]) if np.isscalar(v) else np.ravel(v) for v in obs.values()])
+
+
+def _spec_size(spec):
+    return int(sum(np.prod(s.shape) for s in spec))
+
+
+def run_dm_policy(env, policy_fn, params, buffer, max_interactions, with_frames=False):
+    """Roll the MPC policy in the environment, feeding it the normalised history buffer."""
+    states, actions, rewards, frames = [], [], [], []
+    state_size = _spec_size(env.observation_spec().values())
+    action_size = _spec_size([env.action_spec()])
+    buffer.clear()
+    buffer.append_state(np.zeros(state_size, np.float32))
+    buffer.append_action(np.zeros(action_size, np.float32))
+    timestep = env.reset()
+    t = 0
+    while (not timestep.last()) and (t < max_interactions):
+        x = flatten_tree_obs(timestep.observation)
+        buffer.append_state(x)
+        u = policy_fn(params, buffer.get_state_data(), buffer.get_action_data())
+        u = u.detach().cpu().numpy() if torch.is_tensor(u) else np.asarray(u)
+        buffer.append_action(u)
+        timestep = env.step(u)
+        t += 1
+        if with_frames and (len(frames) < env.physics.data.time * 30):
+            frames.append(env.physics.render(camera_id=0, width=240))
+        states.append(x)
+        actions.append(u)
+        rewards.append(timestep.reward)
+    return np.array(states), np.array(actions), frames, rewards
+
+
+def avg_run_policy(env, policy_fn, params, buffer, num_runs, max_interactions):
+    """reference utils.avg_run_dm_policy (utils.py:294-308): running mean of the episode returns."""
+    avg_reward = 0.0
+    for run in range(1, num_runs + 1):
+        _, _, _, rwd_list = run_dm_policy(env=env, policy_fn=policy_fn, params=params,
+                                          buffer=buffer, max_interactions=max_interactions)
+        avg_reward += (sum(rwd_list) - avg_reward) / run
+    return avg_reward

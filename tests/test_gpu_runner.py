@@ -1,0 +1,172 @@
+"""N1/N3/N4 end to end on the GPU: trajectory file -> loader -> runners (gan and l2) with a synthetic
+dm_control-protocol environment -> saved artefacts; dynamics trainer against the oracle loop."""
+
+import collections
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import gan_mpc_oracle as orc
+from gan_mpc_amd import optim, params as P, utils
+from gan_mpc_amd.gan import runner as gan_runner
+from gan_mpc_amd.norm import dynamics_trainer, runner as l2_runner
+
+pytestmark = pytest.mark.gpu
+CFG = os.path.join(os.path.dirname(__file__), "golden", "runner_config.yaml")
+N, M = 4, 2
+
+
+class _Spec:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class LinearEnv:
+    """x' = A x + B u, reward = 1 - |x|^2/100; the dm_control protocol the runners use."""
+    TimeStep = collections.namedtuple("TimeStep", "observation reward is_last")
+
+    class _TS:
+        def __init__(self, obs, reward, last):
+            self.observation, self.reward, self._last = obs, reward, last
+
+        def last(self):
+            return self._last
+
+    def __init__(self, seed=0, episode_len=20):
+        rng = np.random.default_rng(seed)
+        self.A = np.eye(N) * 0.95 + 0.02 * rng.standard_normal((N, N))
+        self.B = 0.1 * rng.standard_normal((N, M))
+        self.rng, self.episode_len = rng, episode_len
+
+    def observation_spec(self):
+        return collections.OrderedDict(position=_Spec((2,)), velocity=_Spec((2,)))
+
+    def action_spec(self):
+        return _Spec((M,))
+
+    def _obs(self):
+        return collections.OrderedDict(position=self.x[:2].copy(), velocity=self.x[2:].copy())
+
+    def reset(self):
+        self.x, self.t = self.rng.standard_normal(N), 0
+        return self._TS(self._obs(), 0.0, False)
+
+    def step(self, u):
+        self.x = self.A @ self.x + self.B @ np.asarray(u, np.float64)
+        self.t += 1
+        return self._TS(self._obs(), float(1.0 - self.x @ self.x / 100.0), self.t >= self.episode_len)
+
+
+def _write_dataset(tmp_path, ntraj=4, L=40):
+    env = LinearEnv(seed=5, episode_len=L)
+    rng = np.random.default_rng(9)
+    S, U, R = [], [], []
+    for _ in range(ntraj):
+        ts = env.reset()
+        s, a, r = [], [], []
+        for _ in range(L):
+            x = dynamics_trainer.flatten_tree_obs(ts.observation)
+            u = np.tanh(rng.standard_normal(M))
+            ts = env.step(u)
+            s.append(x.tolist()); a.append(u.tolist()); r.append(20.0 + ts.reward)
+        S.append(s); U.append(a); R.append(r)
+    path = tmp_path / "trajectories.json"
+    path.write_text(json.dumps({"states": S, "actions": U, "rewards": R}))
+    return str(path)
+
+
+def test_dynamics_trainer_matches_the_oracle_loop():
+    """train_params == reference loop: sample minibatches, mean loss -> grads -> clip+Adam, with the
+    teacher-forcing schedule (id + up) <= num_updates * factor (dynamics_trainer.py:93-124)."""
+    config = utils.get_config(CFG)
+    policy, _, _ = l2_runner.get_policy(config, N, M)
+    params = l2_runner.get_params(policy, config, N, M)
+    last = f"Dense_{config.mpc.model.dynamics.mlp.num_layers - 1}"
+    params["dynamics_params"]["params"][last]["kernel"] *= 0.1
+    dc = config.mpc.train.dynamics
+    opt = optim.get_optimizer(list(params.keys()), dc.no_grads, dc.learning_rate)
+    assert opt.trainable_keys == ("dynamics_params",)
+    dparams = policy.to_device_params(params)
+    opt_state = opt.init(dparams)
+    rng = np.random.default_rng(2)
+    D, S = 16, config.mpc.horizon
+    X = rng.standard_normal((D, S, N)).astype(np.float32)
+    U = np.tanh(rng.standard_normal((D, S, M))).astype(np.float32)
+    Y = (X + 0.1 * rng.standard_normal((D, S, N))).astype(np.float32)
+    before_other = dparams.flat[:dparams.offsets["dynamics_params"]].clone()
+    new, opt_state, losses = dynamics_trainer.train_params(
+        (policy, opt), opt_state, dparams, (X, U, Y), num_updates=2, batch_size=4,
+        discount_factor=dc.discount_factor, teacher_forcing_factor=0.5, key=13, id=0)
+    assert len(losses) == 2 and opt_state["count"] == 8
+    # oracle loop, float64, same minibatches and schedule
+    dyn = [(W.astype(np.float64), b.astype(np.float64)) for W, b in
+           P.tree_to_layers(params["dynamics_params"])]
+    dims = P.mlp_dims(params["dynamics_params"])
+    theta = P.pack_mlp(params["dynamics_params"]).astype(np.float64)
+    theta0 = theta.copy()
+    mm, vv = np.zeros_like(theta), np.zeros_like(theta)
+    r2 = np.random.default_rng(13)
+    k, ref_losses = 0, []
+    for up in (1, 2):
+        perm = r2.choice(D, size=(D // 4, 4))
+        tf = (0 + up) <= (2 * 0.5)
+        ls = []
+        for p in perm:
+            dyn = [(W.astype(np.float64), b.astype(np.float64)) for W, b in
+                   P.tree_to_layers(P.unpack_mlp(theta.astype(np.float32), dims))]
+            l, g = orc.dynamics_fit_loss_and_grad(dyn, X[p].astype(np.float64), U[p].astype(np.float64),
+                                                  Y[p].astype(np.float64), dc.discount_factor, tf)
+            flat = np.concatenate([t.ravel() for Wb in g for t in Wb])
+            k += 1
+            theta, mm, vv = orc.adam_clip_step(theta, flat, mm, vv, k, dc.learning_rate)
+            ls.append(l)
+        ref_losses.append(np.mean(ls))
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-3)
+    got = new.view("dynamics_params").cpu().numpy()
+    disp_ref, disp_got = theta - theta0, got - theta0
+    big = np.abs(disp_ref) > 0.5 * np.abs(disp_ref).max()
+    assert np.abs(disp_got[big] - disp_ref[big]).max() < 0.05 * np.abs(disp_ref).max()
+    assert torch.equal(before_other, new.flat[:new.offsets["dynamics_params"]])   # masked leaves
+    # predict_loss: the single-sequence entry point equals the oracle on that sequence
+    l1 = dynamics_trainer.predict_loss(policy, params, X[0], U[0], Y[0], 0.9, False)
+    dyn0 = [(W.astype(np.float64), b.astype(np.float64)) for W, b in
+            P.tree_to_layers(params["dynamics_params"])]
+    ref1, _ = orc.dynamics_fit_loss_and_grad(dyn0, X[:1].astype(np.float64), U[:1].astype(np.float64),
+                                             Y[:1].astype(np.float64), 0.9, False)
+    assert abs(float(l1) - ref1) < 1e-5 * abs(ref1)
+
+
+@pytest.mark.parametrize("kind", ["gan", "l2"])
+def test_runner_end_to_end(kind, tmp_path, capsys):
+    path = _write_dataset(tmp_path)
+    env = LinearEnv(seed=1, episode_len=15)
+    mod = gan_runner if kind == "gan" else l2_runner
+    out_dir = mod.run(CFG, dataset_path=path, env=env, save_dir=str(tmp_path / "models" / kind))
+    assert os.path.basename(out_dir) == "0"
+    files = set(os.listdir(out_dir))
+    expect = {"config.json", "params.npz", "cost_train_losses.json", "cost_test_losses.json",
+              "dynamics_env_rewards.json", "dynamics_train_losses.json", "dynamics_test_losses.json"}
+    if kind == "gan":
+        expect |= {"critic_train_losses.json", "critic_test_losses.json"}
+    assert expect <= files
+    cfg = json.load(open(os.path.join(out_dir, "config.json")))
+    assert cfg["seed"] == 3 and set(cfg["loss"]) == ({"dynamics", "cost", "critic"} if kind == "gan"
+                                                    else {"dynamics", "cost"})
+    assert np.isfinite(cfg["reward"]) and cfg["policy"]["horizon"] == 6
+    cost_losses = json.load(open(os.path.join(out_dir, "cost_train_losses.json")))
+    assert len(cost_losses) == 2 and np.isfinite(cost_losses).all()       # 2 epochs x 1 update
+    dyn_losses = json.load(open(os.path.join(out_dir, "dynamics_train_losses.json")))
+    assert len(dyn_losses) == 1 + 2 * 2 and np.isfinite(dyn_losses).all()  # default 0.0 + epochs x updates
+    rewards = json.load(open(os.path.join(out_dir, "dynamics_env_rewards.json")))
+    assert len(rewards) == 1 + 2 and len(rewards[1]) == 12                 # max_interactions_per_episode
+    tree = utils.load_params(os.path.join(out_dir, "params.npz"))
+    assert tree["mpc_weights"].shape == (3,)
+    assert tree["dynamics_params"]["params"]["Dense_0"]["kernel"].shape == (N + M, 32)
+    assert ("critic_params" in tree) == (kind == "gan")
+    # a second run lands in the next numbered directory
+    out2 = mod.run(CFG, dataset_path=path, env=None, save_dir=str(tmp_path / "models" / kind))
+    assert os.path.basename(out2) == "1"
+    assert "epoch: 2" in capsys.readouterr().out
