@@ -14,7 +14,7 @@
 
 // launchers defined in the kernel translation units ---------------------------------------------
 void gmpc_launch_rollout(const TrajArgs&, hipStream_t);
-void gmpc_launch_linesearch(const TrajArgs&, hipStream_t);
+int gmpc_launch_linesearch(const TrajArgs&, const LsWork&, hipStream_t);
 void gmpc_launch_masks(int, int, int, int, const MlpDesc&, const float*, const float*, uint32_t*,
                        hipStream_t);
 int gmpc_launch_linearize(int, int, int, int, const MlpDesc&, const uint32_t*, const int*, float*,
@@ -157,6 +157,7 @@ struct gmpc_ctx {
   // critic workspace
   float *critT, *gates, *cs, *hp, *hT, *dz, *hacts, *hdels, *dhT, *cscore, *closs;
   int hstride;
+  LsWork lsw{};
   // large-state (n > 64) backward pass
   bool big = false;
   BigWork bw{};
@@ -241,9 +242,21 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
   c->linpad_floats = gmpc_linpad_floats(&c->sh);
   A_(linpad, c->linpad_floats);
   A_(masks, B * T * Lh * GMPC_MW);
-  A_(maskc, B * T * Lh * GMPC_MW);
-  A_(Xc, B * (T + 1) * n);
-  A_(Uc, B * T * m);
+  // line-search candidates: GMPC_LS_ITEMS per trajectory
+  A_(maskc, GMPC_LS_ITEMS * B * T * Lh * GMPC_MW);
+  A_(Xc, GMPC_LS_ITEMS * B * (T + 1) * n);
+  A_(Uc, GMPC_LS_ITEMS * B * T * m);
+  for (int i = 0; i < 2; ++i) {
+    if (!rc) rc = dalloc(c, &c->lsw.item_b[i], GMPC_LS_ITEMS * B);
+    if (!rc) rc = dalloc(c, &c->lsw.item_k[i], GMPC_LS_ITEMS * B);
+  }
+  if (!rc) rc = dalloc(c, &c->lsw.first, B);
+  if (!rc) rc = dalloc(c, &c->lsw.cnt, B);
+  if (!rc) rc = dalloc(c, &c->lsw.kfirst, B);
+  if (!rc) rc = dalloc(c, &c->lsw.prevk, B);
+  if (!rc) rc = dalloc(c, &c->lsw.counts, GMPC_LS_ROUNDS_MAX + 1);
+  if (!rc) rc = dalloc(c, &c->lsw.run, B);
+  if (!rc) rc = dalloc(c, &c->lsw.objc, GMPC_LS_ITEMS * B);
   c->big = s.n > 64;
   if (!c->big) {
     A_(AB, B * T * n * nm);
@@ -533,6 +546,8 @@ extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float*
   ls.obj_step = c->obj_step; ls.U_step = c->U_step; ls.iters = c->iters;
   ls.alpha_0 = opts->alpha_0; ls.alpha_min = opts->alpha_min;
   std::vector<int> hcont(B);
+  // a fresh solve starts its first line search with a single full step per trajectory
+  HIP_TRY(hipMemsetAsync(c->lsw.prevk, 0, B * sizeof(int), s));
   for (int it = 0; it < opts->maxiter; ++it) {
     // stop as soon as every trajectory has stopped (one small readback per iteration)
     HIP_TRY(hipMemcpyAsync(hcont.data(), c->cont, B * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -542,7 +557,9 @@ extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float*
     if (!any) break;
     {
       ProfScope ps(c, PROF_LINESEARCH, s);
-      gmpc_launch_linesearch(ls, s);
+      if (gmpc_launch_linesearch(ls, c->lsw, s) != 0)
+        return fail(GMPC_EINVAL, "line search: alpha_0 / alpha_min need more than %d rounds",
+                    GMPC_LS_ROUNDS_MAX);
     }
     TRY(backward_pass(c, B, c->Xs, c->Us, c->goals, c->cont, c->Ks, c->ks, c->grads, c->adjs, c->AB,
                       c->cont, opts, s));

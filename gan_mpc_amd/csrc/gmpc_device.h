@@ -171,7 +171,25 @@ struct TrajArgs {
   int* iters;           // [B] in/out
   float alpha_0, alpha_min;
   int aw, pw;           // LDS sizing (float4 counts): activation buffers, partial-sum buffer
+  // line search: the work list of this round; slot = one (trajectory, halving count) candidate,
+  // candidate i writes Xc / Uc / maskc / objc at index i
+  const int* item_b; const int* item_k; const int* nitems;
+  float* objc;
 };
+
+#define GMPC_LS_ITEMS 8   // candidates per trajectory held at once by the line search
+
+// device workspace of the round-based line search (gmpc_traj.hip)
+struct LsWork {
+  int* item_b[2]; int* item_k[2];   // ping-pong work lists [maxB * GMPC_LS_ITEMS]
+  int* first; int* cnt; int* kfirst;   // [maxB] this round's candidates of trajectory b: items
+                                       // first .. first+cnt-1 = halvings kfirst .. kfirst+cnt-1
+  int* prevk;                       // [maxB] halving count accepted by the previous line search
+  int* counts;                      // [GMPC_LS_ROUNDS_MAX + 1] items per round
+  int* run;                         // [maxB]
+  float* objc;                      // [maxB * GMPC_LS_ITEMS]
+};
+#define GMPC_LS_ROUNDS_MAX 40
 
 struct RiccatiArgs {
   int B, n, m, T, mode;

@@ -57,10 +57,13 @@ __device__ __forceinline__ void hidden_layer(const float* W, const float* bias, 
                             fmaxf(acc[0].w, 0.f));
 }
 
+#ifndef GMPC_TRAJ_MINW
+#define GMPC_TRAJ_MINW 4
+#endif
 #define GMPC_TRAJ_THREADS 512   // k_traj: 8 waves, the upper 4 take the second half of every K range
 
 template <bool LS>
-__global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
+__global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(TrajArgs a) {
   // dynamic LDS: actA | actB (aw float4 each: max(n+m, widest layer)) | part (pw) | ksp (256) | xcur (n)
   extern __shared__ __attribute__((aligned(16))) char smem_traj[];
   float4* const actA = reinterpret_cast<float4*>(smem_traj);
@@ -68,13 +71,30 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
   float4* const part = actB + a.aw;
   float4* const ksp = part + a.pw;
   float4* const xcur = ksp + GMPC_THREADS;
-  __shared__ float s_obj[GMPC_TB], s_objold[GMPC_TB], s_alpha[GMPC_TB], s_ustep[GMPC_TB];
-  __shared__ float s_us[GMPC_TRAJ_THREADS / 64];
-  __shared__ int s_run[GMPC_TB], s_acc[GMPC_TB], s_ever[GMPC_TB], s_any;
+  __shared__ float s_alpha[GMPC_TB];
+  __shared__ int s_bi[GMPC_TB], s_in[GMPC_TB];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = a.n, m = a.m, T = a.T;
+  // slot c of this block: plain rollout -> trajectory b0 + c; line search -> item b0 + c of the
+  // round's work list, i.e. one (trajectory, step size) candidate
   const int b0 = blockIdx.x * GMPC_TB;
+  if (LS) {
+    const int cnt = *a.nitems;
+    if (b0 >= cnt) return;
+    if (tid < GMPC_TB) {
+      const int it = min(b0 + tid, cnt - 1);
+      s_bi[tid] = a.item_b[it];
+      s_in[tid] = (b0 + tid) < cnt;
+      float al = a.alpha_0;
+      for (int k = a.item_k[it]; k > 0; --k) al *= 0.5f;
+      s_alpha[tid] = al;
+    }
+  } else if (tid < GMPC_TB) {
+    s_bi[tid] = min(b0 + tid, a.B - 1);
+    s_in[tid] = (b0 + tid) < a.B;
+  }
+  __syncthreads();
   // Component c of an LDS float4 is always addressed as a float ([k*4 + c]) when c is a run-time
   // value: hipcc (ROCm 7.2) lowers `c == 0 ? v.x : ...` on an LDS reference with a lane-varying c
   // into a branch tree that gives lanes with c == 3 the .z address (seen in the ISA and on the GPU).
@@ -83,37 +103,19 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
   const float* const pf = reinterpret_cast<const float*>(part);
   // trajectory c of this block (reads of the tail block are clamped); no private arrays: a
   // dynamically indexed register array would live in scratch
-  auto BI = [&](int c) -> int { const int b = b0 + c; return b < a.B ? b : a.B - 1; };
-  auto INB = [&](int c) -> bool { return (b0 + c) < a.B; };
+  auto BI = [&](int c) -> int { return s_bi[c]; };
+  auto INB = [&](int c) -> bool { return s_in[c] != 0; };
+  // candidate (item) index of slot c: where the line search writes X / U / masks / objective
+  auto CI = [&](int c) -> size_t { return (size_t)(b0 + c); };
   const int Lh = a.dyn.L - 1;
   const size_t mstride = (size_t)T * Lh * GMPC_MW;   // mask words per trajectory
   const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]), w2 = sigmoidf_(a.mpc_w[2]);
 
-  if (LS) {
-    if (tid < GMPC_TB) {
-      const int b = BI(tid);
-      const bool act = INB(tid) && (a.active == nullptr || a.active[b] != 0);
-      float o = a.obj[b];
-      if (isnan(o)) o = INFINITY;
-      s_objold[tid] = o;
-      s_alpha[tid] = a.alpha_0;
-      s_run[tid] = (act && a.alpha_0 > a.alpha_min) ? 1 : 0;
-      s_acc[tid] = 0;
-      s_ever[tid] = 0;
-      s_ustep[tid] = 0.f;
-      if (act) a.iters[b] += 1;
-    }
-    __syncthreads();
-    if (tid == 0) s_any = s_run[0] | s_run[1] | s_run[2] | s_run[3];
-    __syncthreads();
-  }
-
-  while (true) {
-    if (LS && !s_any) break;
-    // bit c set: trajectory c writes its outputs in this pass
+  {
+    // bit c set: slot c writes its outputs
     unsigned wbits = 0;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) wbits |= ((LS ? (s_run[c] != 0) : INB(c)) ? 1u : 0u) << c;
+    for (int c = 0; c < 4; ++c) wbits |= (INB(c) ? 1u : 0u) << c;
     // ---- initial state
     for (int i = tid; i < n; i += blockDim.x) {
       const float* xs = LS ? a.X : a.x0;
@@ -133,22 +135,31 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
     for (int t = 0; t < T; ++t) {
       // ---- controls and layer-0 input
       for (int i = tid; i < n; i += blockDim.x) actA[i] = xcur[i];
-      if (tid < GMPC_TB * m) {
-        const int c = tid / m, j = tid % m;
-        const int bc = BI(c);
-        const size_t ub = ((size_t)bc * T + t) * m + j;
-        float u;
-        if (LS) {
+      if (LS) {
+        // u = U + alpha k + K (x - X_nominal): 16 lanes share one (slot, control) inner product, so
+        // the n gain / state loads of a control are issued together instead of one after another
+        const int l16 = tid & 15;
+        for (int p = tid >> 4; p < GMPC_TB * m; p += GMPC_TRAJ_THREADS >> 4) {
+          const int c = p / m, j = p - c * m;
+          const int bc = BI(c);
+          const size_t ub = ((size_t)bc * T + t) * m + j;
           const float* Kr = a.Kg + ub * n;
           const float* Xo = a.X + ((size_t)bc * (T + 1) + t) * n;
-          float du = s_alpha[c] * a.kg[ub];
-          for (int i = 0; i < n; ++i) du = fmaf(Kr[i], xf[i * 4 + c] - Xo[i], du);
-          u = a.Uio[ub] + du;
-          if ((wbits >> c) & 1u) a.Uc[ub] = u;
-        } else {
-          u = a.U[ub];
+          float du = 0.f;
+          for (int i = l16; i < n; i += 16) du = fmaf(Kr[i], xf[i * 4 + c] - Xo[i], du);
+          du += __shfl_xor(du, 8);
+          du += __shfl_xor(du, 4);
+          du += __shfl_xor(du, 2);
+          du += __shfl_xor(du, 1);
+          if (l16 == 0) {
+            const float u = a.Uio[ub] + fmaf(s_alpha[c], a.kg[ub], du);
+            if ((wbits >> c) & 1u) a.Uc[(CI(c) * T + t) * m + j] = u;
+            aAf[(n + j) * 4 + c] = u;
+          }
         }
-        aAf[(n + j) * 4 + c] = u;
+      } else if (tid < GMPC_TB * m) {
+        const int c = tid / m, j = tid % m;
+        aAf[(n + j) * 4 + c] = a.U[((size_t)BI(c) * T + t) * m + j];
       }
       __syncthreads();
       // ---- stage cost of (x_t, u_t): wave c (< 4) handles trajectory c
@@ -205,7 +216,8 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
         float* Xo = LS ? a.Xc : a.X;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if ((wbits >> c) & 1u) Xo[((size_t)BI(c) * (T + 1) + t + 1) * n + i] = f4get(v, c);
+          if ((wbits >> c) & 1u)
+            Xo[((LS ? CI(c) : (size_t)BI(c)) * (T + 1) + t + 1) * n + i] = f4get(v, c);
       }
       __syncthreads();
     }
@@ -238,77 +250,131 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS) void k_traj(TrajArgs a) {
             if (a.costs) a.costs[(size_t)BI(c) * (T + 1) + T] = cst;
             a.obj[BI(c)] = objacc;
           }
-        } else {
-          s_obj[c] = objacc;
-        }
-      }
-    }
-    if (!LS) break;
-    __syncthreads();
-    // ---- accept / backtrack decision per trajectory
-    if (tid < GMPC_TB) {
-      const int c = tid;
-      s_acc[c] = 0;
-      if (s_run[c]) {
-        const float oo = s_objold[c];
-        float on = s_obj[c];
-        if (isnan(on)) on = oo;
-        const bool acc = on < oo;
-        s_alpha[c] *= 0.5f;
-        const float objr = fminf(on, oo);
-        if (acc) {
-          s_acc[c] = 1;
-          s_ever[c] = 1;
-          a.obj[BI(c)] = on;
-          a.obj_step[BI(c)] = fabsf(on - oo);
-        }
-        s_run[c] = ((objr >= oo) && (s_alpha[c] > a.alpha_min)) ? 1 : 0;
-      }
-    }
-    __syncthreads();
-    // ---- commit accepted candidates
-    for (int c = 0; c < GMPC_TB; ++c) {
-      if (!s_acc[c]) continue;
-      const size_t b = BI(c);
-      float* Xd = a.X + b * (T + 1) * n;
-      const float* Xs = a.Xc + b * (T + 1) * n;
-      for (int e = n + tid; e < (T + 1) * n; e += blockDim.x) Xd[e] = Xs[e];
-      float us = 0.f;
-      float* Ud = a.Uio + b * T * m;
-      const float* Us = a.Uc + b * T * m;
-      for (int e = tid; e < T * m; e += blockDim.x) {
-        const float un = Us[e], d = un - Ud[e];
-        us = fmaf(d, d, us);
-        Ud[e] = un;
-      }
-      uint32_t* Md = a.masks + b * T * Lh * GMPC_MW;
-      const uint32_t* Ms = a.maskc + b * T * Lh * GMPC_MW;
-      for (int e = tid; e < T * Lh * GMPC_MW; e += blockDim.x) Md[e] = Ms[e];
-      us = wave_sum(us);
-      if (lane == 0) s_us[wave] = us;
-      __syncthreads();  // s_acc is block-uniform, so every thread reaches this barrier
-      if (tid == 0)
-        s_ustep[c] = ((s_us[0] + s_us[1]) + (s_us[2] + s_us[3])) + ((s_us[4] + s_us[5]) + (s_us[6] + s_us[7]));
-    }
-    if (tid == 0) s_any = s_run[0] | s_run[1] | s_run[2] | s_run[3];
-    __syncthreads();
-  }
-  if (LS) {
-    __syncthreads();
-    if (tid < GMPC_TB && INB(tid)) {
-      const int b = BI(tid);
-      const bool act = (a.active == nullptr || a.active[b] != 0);
-      if (act) {
-        a.alpha[b] = s_alpha[tid];
-        if (s_ever[tid]) {
-          a.U_step[b] = sqrtf(s_ustep[tid]);
-        } else {
-          a.U_step[b] = 0.f;
-          a.obj_step[b] = 0.f;
+        } else if (INB(c)) {
+          a.objc[CI(c)] = objacc;
         }
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round-based backtracking line search (trajax line_search_ddp: alpha = alpha_0, alpha_0/2, ... while
+// alpha > alpha_min, the first candidate whose objective decreases is taken).  The halvings of one
+// trajectory are independent rollouts, so a round evaluates several of them speculatively
+// (k_traj<true> over a work list of (trajectory, halving count) candidates) and k_ls_decide picks,
+// per trajectory, the LARGEST accepted step of the round -- the candidate the sequential loop would
+// have stopped at -- commits it, or queues the next 4 halvings.  The first round of a trajectory
+// covers the halvings up to the one its previous line search accepted (1 candidate for a
+// well-conditioned problem that takes full steps, up to 8 for one that backtracks deeply), so the
+// rollouts stay close to the sequential loop's count while the launches drop from up to 15
+// dependent rollouts to 1-3 rounds.  Nothing is read back by the host.
+// ------------------------------------------------------------------------------------------------
+#define GMPC_LS_NEXT 4   // candidates queued per trajectory after a round without an accepted step
+
+__global__ void k_ls_init(int B, const int* active, float alpha_0, float alpha_min, int k_max, int* iters,
+                          int* run, int* item_b, int* item_k, int* first, int* cnt, int* kfirst,
+                          const int* prevk, int* count, float* alpha, float* U_step, float* obj_step) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (active != nullptr && active[b] == 0) { run[b] = 0; return; }
+  iters[b] += 1;
+  if (alpha_0 > alpha_min) {
+    int R = prevk[b] + 1;
+    R = R < 1 ? 1 : R;
+    R = R > GMPC_LS_ITEMS ? GMPC_LS_ITEMS : R;
+    R = R > k_max ? k_max : R;
+    run[b] = 1;
+    const int pos = atomicAdd(count, R);
+    for (int j = 0; j < R; ++j) { item_b[pos + j] = b; item_k[pos + j] = j; }
+    first[b] = pos;
+    cnt[b] = R;
+    kfirst[b] = 0;
+  } else {
+    run[b] = 0;
+    alpha[b] = alpha_0;
+    U_step[b] = 0.f;
+    obj_step[b] = 0.f;
+  }
+}
+
+struct LsDecideArgs {
+  int n, m, T, Lh, k_max;
+  float alpha_0;
+  int* first; int* cnt; int* kfirst; int* prevk; int* run;
+  const float* objc; const float* Xc; const float* Uc; const uint32_t* maskc;
+  float* X; float* U; uint32_t* masks;
+  float* obj; float* obj_step; float* U_step; float* alpha;
+  int* next_item_b; int* next_item_k; int* next_count;
+};
+
+__global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (a.run[b] == 0) return;
+  __shared__ int s_acc;
+  __shared__ float s_us[GMPC_THREADS / 64];
+  const int f = a.first[b];
+  __syncthreads();            // first[b] is rewritten by thread 0 below
+  if (tid == 0) {
+    float oo = a.obj[b];
+    if (isnan(oo)) oo = INFINITY;
+    const int R = a.cnt[b], k0 = a.kfirst[b];
+    int acc = -1;
+    float on_acc = 0.f;
+    for (int j = 0; j < R; ++j) {
+      float on = a.objc[f + j];
+      if (isnan(on)) on = oo;
+      if (on < oo) { acc = j; on_acc = on; break; }
+    }
+    auto halved = [&](int k) { float al = a.alpha_0; for (; k > 0; --k) al *= 0.5f; return al; };
+    if (acc >= 0) {
+      a.obj[b] = on_acc;
+      a.obj_step[b] = fabsf(on_acc - oo);
+      a.alpha[b] = halved(k0 + acc + 1);
+      a.prevk[b] = k0 + acc;
+      a.run[b] = 0;
+    } else if (k0 + R >= a.k_max) {      // every step size down to alpha_min failed
+      a.alpha[b] = halved(a.k_max);
+      a.U_step[b] = 0.f;
+      a.obj_step[b] = 0.f;
+      a.prevk[b] = a.k_max - 1;
+      a.run[b] = 0;
+    } else {
+      const int left = a.k_max - (k0 + R);
+      const int nr = left < GMPC_LS_NEXT ? left : GMPC_LS_NEXT;
+      const int pos = atomicAdd(a.next_count, nr);
+      for (int j = 0; j < nr; ++j) { a.next_item_b[pos + j] = b; a.next_item_k[pos + j] = k0 + R + j; }
+      a.first[b] = pos;
+      a.cnt[b] = nr;
+      a.kfirst[b] = k0 + R;
+    }
+    s_acc = acc;
+  }
+  __syncthreads();
+  const int acc = s_acc;
+  if (acc < 0) return;
+  // commit candidate f + acc as the new iterate
+  const size_t it = (size_t)(f + acc);
+  const int n = a.n, m = a.m, T = a.T;
+  float* Xd = a.X + (size_t)b * (T + 1) * n;
+  const float* Xs = a.Xc + it * (T + 1) * n;
+  for (int e = n + tid; e < (T + 1) * n; e += blockDim.x) Xd[e] = Xs[e];
+  float us = 0.f;
+  float* Ud = a.U + (size_t)b * T * m;
+  const float* Us = a.Uc + it * T * m;
+  for (int e = tid; e < T * m; e += blockDim.x) {
+    const float un = Us[e], d = un - Ud[e];
+    us = fmaf(d, d, us);
+    Ud[e] = un;
+  }
+  const size_t mw = (size_t)T * a.Lh * GMPC_MW;
+  uint32_t* Md = a.masks + (size_t)b * mw;
+  const uint32_t* Ms = a.maskc + it * mw;
+  for (size_t e = tid; e < mw; e += blockDim.x) Md[e] = Ms[e];
+  us = wave_sum(us);
+  if ((tid & 63) == 0) s_us[tid >> 6] = us;
+  __syncthreads();
+  if (tid == 0) a.U_step[b] = sqrtf((s_us[0] + s_us[1]) + (s_us[2] + s_us[3]));
 }
 
 // Forward pass at given (x, u) pairs, masks only: used when gmpc_lqr_backward is handed a
@@ -377,13 +443,38 @@ void gmpc_launch_rollout(const TrajArgs& a0, hipStream_t s) {
   const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
   hipLaunchKernelGGL(k_traj<false>, dim3(grid), dim3(GMPC_TRAJ_THREADS), lds, s, a);
 }
-void gmpc_launch_linesearch(const TrajArgs& a0, hipStream_t s) {
+int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s) {
   TrajArgs a = a0;
   const size_t lds = traj_lds(a);
   static bool attr = false;
   if (!attr) { traj_attr(&k_traj<true>); attr = true; }
-  const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
-  hipLaunchKernelGGL(k_traj<true>, dim3(grid), dim3(GMPC_TRAJ_THREADS), lds, s, a);
+  // halvings allowed by trajax' loop: candidate k runs while alpha_0 / 2^k > alpha_min
+  int k_max = 0;
+  for (float al = a.alpha_0; al > a.alpha_min && k_max < 4096; al *= 0.5f) ++k_max;
+  // worst case: a first round of one candidate, then GMPC_LS_NEXT per round
+  const int rounds = k_max > 0 ? 1 + (k_max - 1 + GMPC_LS_NEXT - 1) / GMPC_LS_NEXT : 0;
+  if (rounds > GMPC_LS_ROUNDS_MAX) return -1;
+  if (hipMemsetAsync(w.counts, 0, (GMPC_LS_ROUNDS_MAX + 1) * sizeof(int), s) != hipSuccess) return -2;
+  hipLaunchKernelGGL(k_ls_init, dim3((a.B + 255) / 256), dim3(256), 0, s, a.B, a.active, a.alpha_0,
+                     a.alpha_min, k_max, a.iters, w.run, w.item_b[0], w.item_k[0], w.first, w.cnt, w.kfirst,
+                     w.prevk, w.counts, a.alpha, a.U_step, a.obj_step);
+  for (int r = 0; r < rounds; ++r) {
+    const int cur = r & 1, nxt = cur ^ 1;
+    a.item_b = w.item_b[cur]; a.item_k = w.item_k[cur]; a.nitems = w.counts + r; a.objc = w.objc;
+    const long max_items = (long)a.B * (r == 0 ? GMPC_LS_ITEMS : GMPC_LS_NEXT);
+    hipLaunchKernelGGL(k_traj<true>, dim3((unsigned)((max_items + GMPC_TB - 1) / GMPC_TB)),
+                       dim3(GMPC_TRAJ_THREADS), lds, s, a);
+    LsDecideArgs d;
+    d.n = a.n; d.m = a.m; d.T = a.T; d.Lh = a.dyn.L - 1; d.k_max = k_max;
+    d.alpha_0 = a.alpha_0;
+    d.first = w.first; d.cnt = w.cnt; d.kfirst = w.kfirst; d.prevk = w.prevk; d.run = w.run;
+    d.objc = w.objc; d.Xc = a.Xc; d.Uc = a.Uc; d.maskc = a.maskc;
+    d.X = a.X; d.U = a.Uio; d.masks = a.masks;
+    d.obj = a.obj; d.obj_step = a.obj_step; d.U_step = a.U_step; d.alpha = a.alpha;
+    d.next_item_b = w.item_b[nxt]; d.next_item_k = w.item_k[nxt]; d.next_count = w.counts + r + 1;
+    hipLaunchKernelGGL(k_ls_decide, dim3(a.B), dim3(GMPC_THREADS), 0, s, d);
+  }
+  return 0;
 }
 void gmpc_launch_masks(int B, int n, int m, int T, const MlpDesc& dyn, const float* X,
                        const float* U, uint32_t* masks, hipStream_t s) {
