@@ -41,6 +41,14 @@ class IlqrOpts(C.Structure):
     ]
 
 
+class ExpertShape(C.Structure):
+    _fields_ = [
+        ("lstm_features", C.c_int), ("head_layers", C.c_int),
+        ("head_dims_x", C.c_int * (GMPC_MAX_LAYERS + 1)),
+        ("head_dims_u", C.c_int * (GMPC_MAX_LAYERS + 1)),
+    ]
+
+
 _P = C.c_void_p
 # name -> (restype, argtypes); exactly the entry points declared in include/gan_mpc_amd.h
 SIGNATURES = {
@@ -57,6 +65,8 @@ SIGNATURES = {
                                   _P, _P]),
     "gmpc_bilevel_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, C.c_float, _P, _P, _P]),
     "gmpc_upper_loss": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "gmpc_expert_rollout": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(ExpertShape), _P, _P, _P, _P, _P]),
+    "gmpc_expert_param_count": (C.c_long, [C.c_int, C.POINTER(ExpertShape)]),
     "gmpc_dynamics_loss_grad": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, C.c_double, C.c_int, _P, _P, _P]),
     "gmpc_polyak": (C.c_int, [_P, C.c_long, _P, _P, C.c_double, _P, _P]),
     "gmpc_critic_loss_grad": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P]),

@@ -384,9 +384,9 @@ extern "C" int gmpc_set_params(gmpc_ctx* c, const float* mpc_w, const float* dyn
   return 0;
 }
 
-static int check_call(gmpc_ctx* c, int B) {
+static int check_call(gmpc_ctx* c, int B, bool need_params = true) {
   if (!c) return fail(GMPC_EINVAL, "ctx is null");
-  if (!c->params_set) return fail(GMPC_EINVAL, "gmpc_set_params has not been called");
+  if (need_params && !c->params_set) return fail(GMPC_EINVAL, "gmpc_set_params has not been called");
   if (B < 1 || B > c->maxB) return fail(GMPC_EINVAL, "B=%d outside [1, max_batch=%d]", B, c->maxB);
   if (hipSetDevice(c->device) != hipSuccess) return fail(GMPC_EHIP, "hipSetDevice failed");
   // hipGetLastError() is per-thread and shared with every other HIP user of the process (torch
@@ -719,6 +719,60 @@ extern "C" int gmpc_upper_loss(gmpc_ctx* c, int B, int loss_kind, const float* d
   if (c->solB != B) return fail(GMPC_EINVAL, "gmpc_ilqr_solve with B=%d must precede this call", B);
   if (!loss) return fail(GMPC_EINVAL, "null argument");
   TRY(upper_loss(c, B, loss_kind, desired, critic, loss, false, static_cast<hipStream_t>(stream)));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// expert sequence model (N2) --------------------------------------------------------------------
+int gmpc_launch_expert(const ExpertArgs&, hipStream_t);
+
+static int check_expert_shape(const gmpc_expert_shape* es, int n, int m) {
+  if (!es) return fail(GMPC_EINVAL, "expert shape is null");
+  if (es->head_layers < 1 || es->head_layers > GMPC_MAX_LAYERS)
+    return fail(GMPC_EINVAL, "expert head_layers=%d outside [1, %d]", es->head_layers, GMPC_MAX_LAYERS);
+  if (es->lstm_features < 0 || es->lstm_features > 128)
+    return fail(GMPC_EINVAL, "expert lstm_features=%d outside [0, 128]", es->lstm_features);
+  const int L = es->head_layers;
+  if (es->head_dims_x[L] != n || es->head_dims_u[L] != m)
+    return fail(GMPC_EINVAL, "expert heads must end in n=%d and m=%d", n, m);
+  if (es->head_dims_x[0] != es->head_dims_u[0] ||
+      (es->lstm_features > 0 && es->head_dims_x[0] != es->lstm_features))
+    return fail(GMPC_EINVAL, "expert heads must start at the width of y");
+  for (int l = 0; l <= L; ++l)
+    if (es->head_dims_x[l] < 1 || es->head_dims_x[l] > 256 || es->head_dims_u[l] < 1 ||
+        es->head_dims_u[l] > 256)
+      return fail(GMPC_EINVAL, "expert head widths must be in [1, 256]");
+  return 0;
+}
+
+extern "C" long gmpc_expert_param_count(int n, const gmpc_expert_shape* es) {
+  if (!es || es->head_layers < 1 || es->head_layers > GMPC_MAX_LAYERS) return -1;
+  const long F = es->lstm_features, h = es->head_dims_x[0];
+  long cnt = F > 0 ? (n + F) * 4 * F + 4 * F : (long)n * h + h;
+  return cnt + mlp_count(es->head_layers, es->head_dims_x) + mlp_count(es->head_layers, es->head_dims_u);
+}
+
+extern "C" int gmpc_expert_rollout(gmpc_ctx* c, int B, int hist, const gmpc_expert_shape* es,
+                                   const float* expert, const float* history, float* goal, float* init_U,
+                                   void* stream) {
+  TRY(check_call(c, B, false));     // the expert model has its own parameters
+  const gmpc_shape& sh = c->sh;
+  if (sh.n > 256) return fail(GMPC_EINVAL, "the expert kernel needs n <= 256 (n = %d)", sh.n);
+  TRY(check_expert_shape(es, sh.n, sh.m));
+  if (hist < 1) return fail(GMPC_EINVAL, "hist=%d: at least one history row is needed (yaml: history >= 1)", hist);
+  if (!expert || !history || !goal || !init_U) return fail(GMPC_EINVAL, "null argument");
+  ExpertArgs a;
+  a.B = B; a.n = sh.n; a.m = sh.m; a.T = sh.T; a.hist = hist; a.F = es->lstm_features;
+  const long F = a.F, h = es->head_dims_x[0];
+  a.Wcat = expert;
+  a.bcat = expert + (F > 0 ? (sh.n + F) * 4 * F : (long)sh.n * h);
+  const float* heads = a.bcat + (F > 0 ? 4 * F : h);
+  bind_mlp(a.hx, es->head_layers, es->head_dims_x, heads, nullptr);
+  bind_mlp(a.hu, es->head_layers, es->head_dims_u, heads + mlp_count(es->head_layers, es->head_dims_x),
+           nullptr);
+  a.history = history; a.goal = goal; a.U = init_U;
+  if (gmpc_launch_expert(a, static_cast<hipStream_t>(stream)) != 0)
+    return fail(GMPC_EINVAL, "expert kernel: unsupported shape");
   HIP_TRY(hipGetLastError());
   return 0;
 }

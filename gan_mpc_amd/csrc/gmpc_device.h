@@ -215,6 +215,17 @@ struct CriticDesc {
   MlpDesc head;              // dims[0] = F ... dims[L] = 1
 };
 
+// expert sequence model (gmpc_expert.hip)
+struct ExpertArgs {
+  int B, n, m, T, hist, F;       // F == 0: the MLP variant (first = Dense(n -> h) + relu)
+  const float* Wcat;             // LSTM: [(n+F)][4F];  MLP: first.W [n][h]
+  const float* bcat;             // LSTM: [4F];         MLP: first.b [h]
+  MlpDesc hx, hu;                // heads: dims[0] = F (or h) ... dims[L] = n / m
+  const float* history;          // [B][hist+1][n]
+  float* goal;                   // [B][T+1][n]
+  float* U;                      // [B][T][m]
+};
+
 // batched "TN" GEMM of the large-state path (gmpc_large.hip)
 struct BgemmArgs {
   int batch, M, N, K;

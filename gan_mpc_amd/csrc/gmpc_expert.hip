@@ -1,0 +1,132 @@
+// Expert sequence model inference: the behaviour-cloning model that turns the state
+// history into the goal states and the initial controls of every MPC solve, i.e. the step right
+// before the hot path inside the same batched function (policy/base.py:41-61, policy/eval.py:87-107).
+//
+// Reference arithmetic: expert/nn.py:43-61 (LSTMCell: x -> OptimizedLSTMCell(F) -> y; next_x =
+// MLPCell(y) + x; u = tanh(MLPCell(y))), :23-40 (StackedMLPCell: y = relu(Dense(x))), :10-20
+// (MLPCell), expert/expert_model.py:60-91 (teacher-forced pass over the history, then `horizon`
+// autoregressive steps).  flax gate order i, f, g, o; zero initial carry.
+//
+// One 512-thread workgroup owns 4 sequences (float4 components) for all hist + T steps: thread j =
+// gate pre-activation j (4F <= 512), the cell update runs as (unit, sequence), then the two heads run
+// side by side, one neuron per thread, the state head on threads 0..255, the action head on 256..511.
+#include "gmpc_device.h"
+
+#define GMPC_EX_THREADS 512
+
+__global__ __launch_bounds__(GMPC_EX_THREADS) void k_expert_seq(ExpertArgs a) {
+  constexpr int SB = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* act = reinterpret_cast<float4*>(smem);        // [n + F]: x | h   (LSTM input image)
+  float4* gbuf = act + (a.n + a.F);                     // [512] gates
+  float4* hA = gbuf + GMPC_EX_THREADS;                  // [512] head activations (x half | u half)
+  float4* hB = hA + GMPC_EX_THREADS;                    // [512]
+  const int tid = threadIdx.x;
+  const int n = a.n, m = a.m, F = a.F, G4 = 4 * F;
+  const int s0 = blockIdx.x * SB;
+  float* actf = reinterpret_cast<float*>(act);
+  float* gbf = reinterpret_cast<float*>(gbuf);
+  const int half = tid >> 8, hj = tid & 255;            // head: 0 = state, 1 = action; neuron index
+  const MlpDesc& hd = half == 0 ? a.hx : a.hu;
+  float c = 0.f;                                        // cell state of (unit tid % F, sequence tid / F)
+  for (int e = tid; e < F * SB; e += blockDim.x) actf[n * SB + e] = 0.f;     // h = 0
+  const int steps = a.hist + a.T;
+  for (int st = 0; st < steps; ++st) {
+    // ---- input: history row while teacher-forced; then the model's own prediction (kept in act)
+    if (st <= a.hist) {
+      // st < hist: history[st]; st == hist: the current state x = history[hist] (eval.py:93-99)
+      for (int e = tid; e < n * SB; e += blockDim.x) {
+        const int sb = e / n, i = e - sb * n;
+        const int s = min(s0 + sb, a.B - 1);
+        const float v = a.history[((size_t)s * (a.hist + 1) + st) * n + i];
+        actf[i * SB + sb] = v;
+        if (st == a.hist && s0 + sb < a.B) a.goal[(size_t)s * (a.T + 1) * n + i] = v;
+      }
+    }
+    __syncthreads();
+    // ---- y: LSTM cell or first dense layer
+    if (F > 0) {
+      if (tid < G4) {
+        const float bj = a.bcat[tid];
+        float4 acc[1] = {make_float4(bj, bj, bj, bj)};
+        dense_rows<1>(a.Wcat, n + F, G4, tid, act, acc);
+        float4 v = acc[0];
+        if (tid >= 2 * F && tid < 3 * F) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+        else { v.x = sigmoidf_(v.x); v.y = sigmoidf_(v.y); v.z = sigmoidf_(v.z); v.w = sigmoidf_(v.w); }
+        gbuf[tid] = v;
+      }
+      __syncthreads();
+      if (tid < F * SB) {
+        const int u = tid % F, sb = tid / F;
+        const float ig = gbf[(0 * F + u) * SB + sb], fg = gbf[(1 * F + u) * SB + sb];
+        const float gg = gbf[(2 * F + u) * SB + sb], og = gbf[(3 * F + u) * SB + sb];
+        c = fg * c + ig * gg;
+        const float h = og * tanhf(c);
+        actf[(n + u) * SB + sb] = h;
+      }
+      __syncthreads();
+      // both heads read y = h
+      if (hj < F) hA[half * 256 + hj] = act[n + hj];
+    } else {
+      const int H0 = a.hx.dims[0];
+      if (tid < H0) {
+        const float bj = a.bcat[tid];
+        float4 acc[1] = {make_float4(bj, bj, bj, bj)};
+        dense_rows<1>(a.Wcat, n, H0, tid, act, acc);
+        const float4 v = make_float4(fmaxf(acc[0].x, 0.f), fmaxf(acc[0].y, 0.f), fmaxf(acc[0].z, 0.f),
+                                     fmaxf(acc[0].w, 0.f));
+        hA[tid] = v;
+        hA[256 + tid] = v;
+      }
+    }
+    __syncthreads();
+    // ---- heads (same depth): state head on threads 0..255, action head on 256..511
+    float4* in = hA;
+    float4* out = hB;
+    const int L = a.hx.L;
+    for (int l = 0; l < L; ++l) {
+      const int K = hd.dims[l], N = hd.dims[l + 1];
+      if (hj < N) {
+        const float bj = hd.b[l][hj];
+        float4 acc[1] = {make_float4(bj, bj, bj, bj)};
+        dense_rows<1>(hd.W[l], K, N, hj, in + half * 256, acc);
+        float4 v = acc[0];
+        if (l < L - 1) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        out[half * 256 + hj] = v;
+      }
+      __syncthreads();
+      float4* tmp = in; in = out; out = tmp;
+    }
+    // ---- outputs: next_x = head_x + x (the next input), u = tanh(head_u)
+    const bool emit = st >= a.hist;
+    const int t = st - a.hist;
+    if (half == 0 && hj < n) {
+      const float4 x = act[hj], o = in[hj];
+      const float4 v = make_float4(o.x + x.x, o.y + x.y, o.z + x.z, o.w + x.w);
+      act[hj] = v;          // own element: read above, written here, by the same thread
+      if (emit) {
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+          if (s0 + cc < a.B) a.goal[((size_t)(s0 + cc) * (a.T + 1) + t + 1) * n + hj] = f4get(v, cc);
+      }
+    } else if (half == 1 && hj < m && emit) {
+      const float4 o = in[256 + hj];
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        if (s0 + cc < a.B) a.U[((size_t)(s0 + cc) * a.T + t) * m + hj] = tanhf(f4get(o, cc));
+    }
+    __syncthreads();
+  }
+}
+
+int gmpc_launch_expert(const ExpertArgs& a, hipStream_t s) {
+  if (a.n > 256 || a.m > 256 || 4 * a.F > GMPC_EX_THREADS) return -1;
+  if (a.hx.L != a.hu.L || a.hx.L < 1) return -1;
+  for (int l = 0; l <= a.hx.L; ++l)
+    if (a.hx.dims[l] > 256 || a.hu.dims[l] > 256) return -1;
+  const size_t lds = ((size_t)(a.n + a.F) + 3 * GMPC_EX_THREADS) * sizeof(float4);
+  hipLaunchKernelGGL(k_expert_seq, dim3((a.B + 3) / 4), dim3(GMPC_EX_THREADS), lds, s, a);
+  return 0;
+}

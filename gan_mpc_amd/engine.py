@@ -45,6 +45,18 @@ def make_shape(n, m, T, dyn_dims, cost_dims, lstm_features=0, head_dims=None):
     return s
 
 
+def make_expert_shape(lstm_features, head_dims_x, head_dims_u):
+    """gmpc_expert_shape: y width (= lstm_features, or the first dense width of the MLP variant),
+    hidden widths, then n / m."""
+    es = _lib.ExpertShape()
+    es.lstm_features = int(lstm_features)
+    assert len(head_dims_x) == len(head_dims_u)
+    es.head_layers = len(head_dims_x) - 1
+    for i, (dx, du) in enumerate(zip(head_dims_x, head_dims_u)):
+        es.head_dims_x[i], es.head_dims_u[i] = int(dx), int(du)
+    return es
+
+
 def make_opts(kwargs=None):
     kw = dict(TRAJAX_iLQR_KWARGS)
     if kwargs:
@@ -110,6 +122,8 @@ class Engine:
         return torch.empty(*shape, dtype=dtype, device=self.device)
 
     def to_dev(self, a, dtype=torch.float32):
+        if torch.is_tensor(a):
+            return a.to(device=self.device, dtype=dtype).contiguous()
         return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device).contiguous()
 
     def set_params(self, mpc_w, dyn, cost):
@@ -164,6 +178,17 @@ class Engine:
         _lib.check(self.lib.gmpc_upper_loss(self.ctx, B, int(loss_kind), _ptr(desired), _ptr(critic),
                                             _ptr(loss), self._stream()))
         return loss
+
+    def expert_rollout(self, history, expert_flat, expert_shape):
+        """history (B, hist+1, n) -> goal (B, T+1, n), init_U (B, T, m) from the expert sequence model."""
+        B, hist = history.shape[0], history.shape[1] - 1
+        want = self.lib.gmpc_expert_param_count(self.n, C.byref(expert_shape))
+        assert expert_flat.numel() == want, (expert_flat.numel(), want)
+        goal = self.new(B, self.T + 1, self.n)
+        init_U = self.new(B, self.T, self.m)
+        _lib.check(self.lib.gmpc_expert_rollout(self.ctx, B, hist, C.byref(expert_shape), _ptr(expert_flat),
+                                                _ptr(history), _ptr(goal), _ptr(init_U), self._stream()))
+        return goal, init_U
 
     def dynamics_loss_grad(self, xseq, useq, next_xseq, discount, teacher_forcing):
         """-> (loss_sum[1], grad_sum[dyn_count]) of the multi-step prediction loss over the batch."""

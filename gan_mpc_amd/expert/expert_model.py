@@ -1,12 +1,19 @@
-"""Where goal_xseq / init_useq come from.  In the reference they are produced by a pretrained
-behaviour-cloning sequence model (reference expert/expert_model.py:60-91, expert/nn.py) whose
-parameters are not shipped; that model is the row before the hot path and is not
-rebuilt here.  The policy only needs the protocol below."""
+"""Where goal_xseq / init_useq come from (reference policy/eval.py:87-107, policy/base.py:41-61).
+
+ExpertModel is the reference's behaviour-cloning sequence model (expert/expert_model.py:10-91,
+expert/nn.py:10-163) run on the GPU by gmpc_expert_rollout: the history rows are fed teacher-forced,
+then the model rolls `horizon` steps on its own predictions.  No pretrained parameters ship with
+either repository, so utils.get_expert_model falls back to HoldExpert unless a saved model is found;
+TableExpert serves synthetic workloads and tests."""
 
 import numpy as np
 
+from gan_mpc_amd import nn_init, params as P
+
 
 class ExpertProtocol:
+    needs_engine = False
+
     def init(self, *args):
         return None
 
@@ -45,3 +52,82 @@ class TableExpert(ExpertProtocol):
         idx = self._cursor if self._cursor is not None else np.arange(len(history_X))
         self._cursor = None
         return self.goal[idx], self.init_U[idx]
+
+
+class _ModelSpec:
+    """What expert_nn.StateAction(ScanLSTM | ScanMLP) carries: the architecture."""
+
+    def __init__(self, use, lstm_features, num_layers, num_hidden_units, x_out, u_out):
+        self.use, self.lstm_features = use, int(lstm_features)
+        self.num_layers, self.num_hidden_units = int(num_layers), int(num_hidden_units)
+        self.x_out, self.u_out = int(x_out), int(u_out)
+
+
+class ExpertModel(ExpertProtocol):
+    needs_engine = True
+
+    def __init__(self, config, model):
+        self.config = config
+        self.model = model
+        self._packed = None        # (id(params), device flat vector, shape struct)
+
+    @staticmethod
+    def get_model(model_config, x_size, u_size):
+        """reference expert_model.py:15-37"""
+        if model_config.use == "lstm":
+            c = model_config.lstm
+            return _ModelSpec("lstm", c.lstm_features, c.num_layers, c.num_hidden_units, x_size, u_size)
+        if model_config.use == "mlp":
+            c = model_config.mlp
+            return _ModelSpec("mlp", 0, c.num_layers, c.num_hidden_units, x_size, u_size)
+        raise ValueError("Choose either mlp or lstm model.")
+
+    def init(self, load_params, *args):
+        """reference expert_model.py:39-48.  load_params=True reads the saved parameters of
+        trained_models/expert/<env type>/<env name>/<load_id>/ (params.npz, or the reference's pickled
+        params.npy when that is what is there); otherwise args = (seed, batch, seqlen, x_size) and a
+        fresh flax-style tree is drawn."""
+        from gan_mpc_amd import utils
+        if load_params:
+            config = self.config
+            base = (f"trained_models/expert/{config.env.type}/{config.env.expert.name}/"
+                    f"{config.mpc.model.expert.load_id}/")
+            try:
+                return utils.load_params(base + "params.npz")
+            except FileNotFoundError:
+                return utils.load_params(base + "params.npy", allow_pickle=True)
+        seed = args[0]
+        rng = np.random.default_rng(seed)
+        mdl = self.model
+        if mdl.use == "lstm":
+            F, L, ywidth = mdl.lstm_features, mdl.num_layers, mdl.lstm_features
+            ex = {"lstm": dict(Wx=nn_init.lecun_normal(rng, mdl.x_out, 4 * F),
+                               Wh=nn_init.lecun_normal(rng, F, 4 * F), b=np.zeros(4 * F, np.float32))}
+        else:
+            L, ywidth = mdl.num_layers - 1, mdl.num_hidden_units
+            ex = {"first": (nn_init.lecun_normal(rng, mdl.x_out, ywidth), np.zeros(ywidth, np.float32))}
+        for key, out in (("head_x", mdl.x_out), ("head_u", mdl.u_out)):
+            sizes = [ywidth] + [mdl.num_hidden_units] * (L - 1) + [out]
+            ex[key] = [(nn_init.lecun_normal(rng, a, b), np.zeros(b, np.float32))
+                       for a, b in zip(sizes[:-1], sizes[1:])]
+        return P.expert_oracle_to_tree(ex)
+
+    def _device_params(self, expert_params, engine):
+        from gan_mpc_amd.engine import make_expert_shape
+        if self._packed is None or self._packed[0] is not expert_params:
+            flat, F, dx, du = P.pack_expert(expert_params)
+            self._packed = (expert_params, engine.to_dev(flat), make_expert_shape(F, dx, du))
+        return self._packed[1], self._packed[2]
+
+    def get_goal_states_init_actions(self, history_X, expert_params, engine=None):
+        """Batched policy/eval.py:87-107 on the GPU -> device tensors goal (B, T+1, n), init_U (B, T, m)."""
+        if engine is None:
+            raise ValueError("ExpertModel runs on the GPU: the policy passes its engine")
+        flat, shape = self._device_params(expert_params, engine)
+        return engine.expert_rollout(engine.to_dev(np.asarray(history_X, np.float32)), flat, shape)
+
+    # single-sample API of the reference (expert_model.py:78-91), for parity of the protocol
+    def get_carry_next_state_and_action_seq(self, history_x, expert_params, engine):
+        goal, U = self.get_goal_states_init_actions(np.asarray(history_x, np.float32)[None],
+                                                    expert_params, engine)
+        return goal[0], U[0]

@@ -6,6 +6,10 @@ numpy's, not JAX's threefry: `seed` reproduces within this package, not against 
 import numpy as np
 
 
+def lecun_normal(rng, fan_in, fan_out):
+    return (rng.standard_normal((fan_in, fan_out)) / np.sqrt(fan_in)).astype(np.float32)
+
+
 def dense_tree(rng, dims):
     p = {}
     for k, (a, b) in enumerate(zip(dims[:-1], dims[1:])):

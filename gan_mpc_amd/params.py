@@ -145,3 +145,90 @@ def critic_tree_to_oracle(tree):
         head.append((np.asarray(p[f"Dense_{k}"]["kernel"]), np.asarray(p[f"Dense_{k}"]["bias"])))
         k += 1
     return dict(Wx=Wx, Wh=Wh, b=b, head=head)
+
+
+# ---- expert sequence model (reference expert/nn.py) ----------------------------------------------
+# Tree layout written by this package (and read back tolerantly from a flax checkpoint):
+#   {"params": {"model": {<cell scope>: {"OptimizedLSTMCell_0": {ii..ho}        (LSTM variant)
+#                                        | "Dense_0": {kernel, bias}            (MLP variant)
+#                                        "MLPCell_0": {"Dense_k": ...}          state head
+#                                        "MLPCell_1": {"Dense_k": ...}}}}}      action head
+# The flax auto-names of nn.scan'd cells are recalled, not verified offline, so the
+# reader looks the pieces up by structure: the sub-dict holding ii/if/ig/io, and the two MLPCell
+# scopes in name order.
+EXPERT_CELL_SCOPE = "ScanLSTMCell_0"
+
+
+def _dense_stack(p):
+    out, k = [], 0
+    while f"Dense_{k}" in p:
+        out.append((np.asarray(p[f"Dense_{k}"]["kernel"], np.float32),
+                    np.asarray(p[f"Dense_{k}"]["bias"], np.float32)))
+        k += 1
+    return out
+
+
+def _find_scope(tree, pred):
+    if isinstance(tree, dict):
+        if pred(tree):
+            return tree
+        for v in tree.values():
+            r = _find_scope(v, pred)
+            if r is not None:
+                return r
+    return None
+
+
+def expert_tree_to_oracle(tree):
+    cell = _find_scope(tree, lambda d: any(k.startswith("MLPCell") for k in d))
+    if cell is None:
+        raise KeyError("no MLPCell scopes in expert params")
+    heads = sorted(k for k in cell if k.startswith("MLPCell"))
+    ex = {"head_x": _dense_stack(cell[heads[0]]), "head_u": _dense_stack(cell[heads[1]])}
+    lstm = _find_scope(cell, lambda d: "ii" in d and "hi" in d)
+    if lstm is not None:
+        ex["lstm"] = dict(
+            Wx=np.concatenate([np.asarray(lstm["i" + g]["kernel"], np.float32) for g in GATES], axis=1),
+            Wh=np.concatenate([np.asarray(lstm["h" + g]["kernel"], np.float32) for g in GATES], axis=1),
+            b=np.concatenate([np.asarray(lstm["h" + g]["bias"], np.float32) for g in GATES]))
+    else:
+        ex["first"] = _dense_stack(cell)[0]
+    return ex
+
+
+def expert_oracle_to_tree(ex, scope=EXPERT_CELL_SCOPE):
+    cell = {}
+    if "lstm" in ex:
+        F = ex["lstm"]["Wh"].shape[0]
+        lc = {}
+        for gi, g in enumerate(GATES):
+            lc["i" + g] = {"kernel": np.asarray(ex["lstm"]["Wx"][:, gi * F:(gi + 1) * F])}
+            lc["h" + g] = {"kernel": np.asarray(ex["lstm"]["Wh"][:, gi * F:(gi + 1) * F]),
+                           "bias": np.asarray(ex["lstm"]["b"][gi * F:(gi + 1) * F])}
+        cell["OptimizedLSTMCell_0"] = lc
+    else:
+        cell["Dense_0"] = {"kernel": np.asarray(ex["first"][0]), "bias": np.asarray(ex["first"][1])}
+    for name, key in (("MLPCell_0", "head_x"), ("MLPCell_1", "head_u")):
+        cell[name] = {f"Dense_{k}": {"kernel": np.asarray(W), "bias": np.asarray(b)}
+                      for k, (W, b) in enumerate(ex[key])}
+    return {"params": {"model": {scope: cell}}}
+
+
+def pack_expert(ex):
+    """oracle-style dict (or a tree) -> (flat fp32 vector, lstm_features, head_dims_x, head_dims_u) in
+    the layout of gmpc_expert_rollout."""
+    if "params" in ex:
+        ex = expert_tree_to_oracle(ex)
+    parts = []
+    if "lstm" in ex:
+        F = ex["lstm"]["Wh"].shape[0]
+        parts += [ex["lstm"]["Wx"], ex["lstm"]["Wh"], ex["lstm"]["b"]]
+    else:
+        F = 0
+        parts += [ex["first"][0], ex["first"][1]]
+    for key in ("head_x", "head_u"):
+        for W, b in ex[key]:
+            parts += [W, b]
+    flat = np.concatenate([np.asarray(p, np.float32).reshape(-1) for p in parts])
+    dims = lambda layers: [layers[0][0].shape[0]] + [W.shape[1] for W, _ in layers]
+    return flat, F, dims(ex["head_x"]), dims(ex["head_u"])

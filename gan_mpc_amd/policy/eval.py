@@ -81,8 +81,14 @@ class EvalMPC:
         return self.dynamics_model.get_history_carry(history_x[:-1], history_u, None)
 
     def get_goal_states_init_actions(self, history_X, params):
+        """reference policy/eval.py:87-107, batched: history_X (B, hist+1, n) -> goal, init_U (host
+        arrays from a table / hold expert, device tensors from the GPU sequence model)."""
         expert_params = params.expert_params if isinstance(params, DeviceParams) else params.get(
             "expert_params")
+        if getattr(self.expert_model, "needs_engine", False):
+            dparams = self.to_device_params(params)
+            eng = self.engine_for(len(history_X), dparams)
+            return self.expert_model.get_goal_states_init_actions(history_X, expert_params, engine=eng)
         return self.expert_model.get_goal_states_init_actions(history_X, expert_params)
 
     def _solve(self, params, history_X):

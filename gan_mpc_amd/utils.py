@@ -150,9 +150,18 @@ def load_params(params_path, from_np=True, allow_pickle=False):
 
 
 def get_expert_model(config, x_size, u_size):
-    """reference utils.py:216-227 loads a pretrained behaviour-cloning sequence model; its
-    parameters ship with neither repository.  Until one is given, the goal is "hold
-    the current state" with zero initial controls."""
+    """reference utils.py:216-227: the pretrained behaviour-cloning sequence model saved under
+    trained_models/expert/<env type>/<env name>/<load_id>/ (config.json names its architecture).  No
+    such model ships with either repository; when none is found the goal is "hold the
+    current state" with zero initial controls."""
     from gan_mpc_amd.expert import expert_model
-    del x_size
-    return expert_model.HoldExpert(config.mpc.horizon, u_size)
+    env_type, env_name = config.env.type, config.env.expert.name
+    env_id = config.mpc.model.expert.load_id
+    saved_config_path = f"trained_models/expert/{env_type}/{env_name}/{env_id}/config.json"
+    if not os.path.exists(_abs(saved_config_path)):
+        return expert_model.HoldExpert(config.mpc.horizon, u_size)
+    saved_config = load_json(saved_config_path)
+    model_config = load_config.Config.from_dict(saved_config["model"])
+    nn_model = expert_model.ExpertModel.get_model(model_config=model_config, x_size=x_size,
+                                                  u_size=u_size)
+    return expert_model.ExpertModel(config, nn_model)

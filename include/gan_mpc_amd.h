@@ -158,6 +158,27 @@ int gmpc_adam_clip_step(gmpc_ctx* ctx, long count, float* params, const float* g
                         float* v, float grad_scale, int step, double lr, double max_norm, double b1,
                         double b2, double eps, void* stream);
 
+/* N2: the expert sequence model that produces goal_xseq / init_useq for every solve
+ * (policy/eval.py:87-107 get_goal_states_init_actions; expert/expert_model.py:60-91;
+ * expert/nn.py:10-61).  lstm_features > 0: LSTMCell variant (x -> LSTM(F) -> y), == 0: StackedMLPCell
+ * variant (y = relu(Dense(x)), head_dims[0] = that hidden width).  Both heads are relu MLPs
+ * y -> ... -> n (state, residual: next_x = head + x) and y -> ... -> m (action, tanh).
+ * Flat parameter layout `expert` (flax order, kernel (in,out) then bias):
+ *   LSTM: Wx[n][4F] | Wh[F][4F] | b[4F] (gates i,f,g,o)   or   MLP: W0[n][h] | b0[h]
+ *   then the state head's layers, then the action head's layers.
+ * history [B][hist+1][n] (hist >= 1 teacher-forced rows, then the current state) ->
+ * goal [B][T+1][n] (row 0 = current state), init_U [B][T][m].  Needs n, m, widths <= 256, F <= 128. */
+typedef struct gmpc_expert_shape {
+  int lstm_features;
+  int head_layers;                           /* dense layers per head (>= 1) */
+  int head_dims_x[GMPC_MAX_LAYERS + 1];      /* y width, hidden..., n */
+  int head_dims_u[GMPC_MAX_LAYERS + 1];      /* y width, hidden..., m */
+} gmpc_expert_shape;
+int gmpc_expert_rollout(gmpc_ctx* ctx, int B, int hist, const gmpc_expert_shape* es,
+                        const float* expert, const float* history, float* goal, float* init_U,
+                        void* stream);
+long gmpc_expert_param_count(int n, const gmpc_expert_shape* es);
+
 /* N3: dynamics-model regression, norm/dynamics_trainer.py:14-47 (predict_loss) and
  * :62-86 (batch mean + value_and_grad) with utils.py:230-240 (discounted_sum).  For each of the B
  * sequences: x_in_t = teacher_forcing ? xseq[t] : pred_{t-1} (x_in_0 = xseq[0]),

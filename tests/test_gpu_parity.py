@@ -365,3 +365,33 @@ def test_dynamics_loss_grad(name, tf, S):
         eng.dynamics_loss_grad(d(np.zeros((B, pb["T"] + 1, n), np.float32)),
                                d(np.zeros((B, pb["T"] + 1, m), np.float32)),
                                d(np.zeros((B, pb["T"] + 1, n), np.float32)), gamma, tf)
+
+
+@pytest.mark.parametrize("name,F,hist,hidden,layers", [("c2-cheetah", 128, 1, 128, 3),
+                                                       ("c2-cheetah", 0, 2, 128, 3),
+                                                       ("tiny-ragged", 24, 3, 19, 2),
+                                                       ("wide", 64, 1, 256, 3)])
+def test_expert_rollout(name, F, hist, hidden, layers):
+    """N2: goal states / initial controls from the expert sequence model (expert_model.py:60-91)."""
+    from gan_mpc_amd import params as P
+    from gan_mpc_amd.engine import make_expert_shape
+    pb, _, eng = _setup(name)
+    B, n, m, T = pb["B"], pb["n"], pb["m"], pb["T"]
+    rng = np.random.default_rng(17)
+    ex = orc.make_expert(rng, n, m, lstm_features=F, num_layers=layers, num_hidden_units=hidden)
+    # trained-like residual head so that 50 free-running steps stay O(1)
+    W, b = ex["head_x"][-1]
+    ex["head_x"][-1] = ((0.1 * W).astype(np.float32), (0.1 * b).astype(np.float32))
+    hx = rng.standard_normal((B, hist + 1, n)).astype(np.float32)
+    flat, Fp, dx, du = P.pack_expert(ex)
+    goal, U = eng.expert_rollout(eng.to_dev(hx), eng.to_dev(flat), make_expert_shape(Fp, dx, du))
+    g32, u32 = orc.expert_goal_states_init_actions(ex, hx, T)
+    ex64 = orc.cast_problem(dict(e=ex), np.float64)["e"]
+    g64, u64 = orc.expert_goal_states_init_actions(ex64, hx.astype(np.float64), T)
+    np.testing.assert_array_equal(goal[:, 0].cpu().numpy(), hx[:, -1])
+    gu.assert_parity("goal", goal.cpu().numpy(), g32, g64)
+    gu.assert_parity("init_U", U.cpu().numpy(), u32, u64)
+    assert np.abs(U.cpu().numpy()).max() <= 1.0
+    from gan_mpc_amd import GmpcError
+    with pytest.raises(GmpcError, match="history"):
+        eng.expert_rollout(eng.to_dev(hx[:, :1]), eng.to_dev(flat), make_expert_shape(Fp, dx, du))

@@ -251,3 +251,63 @@ def test_dynamics_fit_gradient_matches_autograd(teacher_forcing):
     for (gW, gb), (W, b) in zip(grads, Ws):
         np.testing.assert_allclose(gW, W.grad.numpy(), rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(gb, b.grad.numpy(), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind", ["lstm", "mlp"])
+def test_expert_rollout_matches_torch_cells(kind):
+    """N2: the oracle's expert roll (expert/nn.py cells, expert_model.py:60-91) against an independent
+    transcription on torch.nn.LSTMCell / Linear (gate order i,f,g,o in both)."""
+    import torch
+    rng = np.random.default_rng(12)
+    n, m, T, B, hist, F, H = 5, 2, 6, 3, 2, 8, 7
+    ex = orc.make_expert(rng, n, m, lstm_features=F if kind == "lstm" else 0, num_layers=3,
+                         num_hidden_units=H, dtype=np.float64, bias_scale=0.3)
+    hx = rng.standard_normal((B, hist + 1, n))
+    goal, U = orc.expert_goal_states_init_actions(ex, hx, T)
+    t = lambda a: torch.tensor(np.asarray(a))
+
+    def mlp(layers, y):
+        for l, (W, b) in enumerate(layers):
+            y = y @ t(W) + t(b)
+            if l < len(layers) - 1:
+                y = torch.relu(y)
+        return y
+
+    if kind == "lstm":
+        cell = torch.nn.LSTMCell(n, F).double()
+        with torch.no_grad():
+            cell.weight_ih.copy_(t(ex["lstm"]["Wx"]).T)
+            cell.weight_hh.copy_(t(ex["lstm"]["Wh"]).T)
+            cell.bias_ih.copy_(t(ex["lstm"]["b"]))
+            cell.bias_hh.zero_()
+    X = t(hx)
+    with torch.no_grad():
+        for b in range(B):
+            # get_history_carry: teacher-forced scan over history_x[:-1]
+            h = torch.zeros(1, F, dtype=torch.float64)
+            c = torch.zeros(1, F, dtype=torch.float64)
+            for s in range(hist):
+                x = X[b, s][None]
+                if kind == "lstm":
+                    h, c = cell(x, (h, c))
+            # the carry's last state is replaced by the current state, then T free-running steps
+            xprev = X[b, hist][None]
+            rows, us = [xprev[0]], []
+            for s in range(T):
+                x = xprev
+                if kind == "lstm":
+                    h, c = cell(x, (h, c))
+                    y = h
+                else:
+                    y = torch.relu(x @ t(ex["first"][0]) + t(ex["first"][1]))
+                xprev = mlp(ex["head_x"], y) + x
+                us.append(torch.tanh(mlp(ex["head_u"], y))[0])
+                rows.append(xprev[0])
+            np.testing.assert_allclose(goal[b], torch.stack(rows).numpy(), rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(U[b], torch.stack(us).numpy(), rtol=1e-10, atol=1e-12)
+    # packing round trip through the flax-style tree
+    from gan_mpc_amd import params as P
+    flat, Fp, dx, du = P.pack_expert(P.expert_oracle_to_tree(ex))
+    flat2, *_ = P.pack_expert(ex)
+    np.testing.assert_array_equal(flat, flat2)
+    assert Fp == (F if kind == "lstm" else 0) and dx[-1] == n and du[-1] == m
