@@ -10,7 +10,8 @@ All inputs are resident in HBM before the timed region.  fp32 throughout (the re
 
   python bench.py --gpus N --steps K --warmup W
 For N > 1 the driver launches one rank per GPU with torch.distributed.run (RCCL); per-GPU work is
-fixed (weak scaling), the only exchange is one all-reduce of the packed critic [loss | grads] buffer.
+fixed (weak scaling), the only exchange is one all-reduce of the packed critic [loss | grads] buffer,
+issued asynchronously so that it overlaps the backward pass.
 Rank 0 prints ONE JSON line.
 """
 
@@ -197,14 +198,17 @@ def main():
     from gan_mpc_amd import _lib
 
     def step(k):
+        # rollout -> critic gradients -> [all-reduce in flight] backward pass -> optimiser: the only
+        # exchange of the step travels over xGMI while the matrix cores run the Jacobian chain
         eng.rollout_cost(x0, U, goal, X=X, costs=costs)
-        eng.lqr_backward(X, U, goal, after_rollout=True, out=bw)
         _lib.check(eng.lib.gmpc_critic_loss_grad(
             eng.ctx, 2 * B, C.c_void_p(xseq.data_ptr()), C.c_void_p(label.data_ptr()),
             C.c_void_p(critic.data_ptr()), C.c_void_p(loss_view.data_ptr()),
             C.c_void_p(grad_view.data_ptr()), eng._stream()))
-        if world > 1:
-            dist.all_reduce(packed)
+        work = dist.all_reduce(packed, async_op=True) if world > 1 else None
+        eng.lqr_backward(X, U, goal, after_rollout=True, out=bw)
+        if work is not None:
+            work.wait()
         eng.adam_clip_step(critic, grad_view, adam_m, adam_v, k + 1, lr=1e-5,
                            grad_scale=1.0 / (2 * B * world))
 
