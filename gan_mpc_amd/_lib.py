@@ -92,6 +92,11 @@ def load():
         raise GmpcError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (make -C gan_mpc_amd/csrc).  gan_mpc_amd has no CPU fallback.")
+    # The process must hold ONE HIP runtime: torch ships its own libamdhip64 and owns the device
+    # buffers this library is handed, so it is loaded first and our shared object binds to that copy.
+    # (Loaded the other way round, /opt/rocm's runtime comes in as a second instance that sees no
+    # device and could not use torch's pointers anyway.)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
