@@ -27,7 +27,9 @@ int gmpc_launch_dynfit(int, int, int, int, const MlpDesc&, const float*, const f
                        int, float*, float*, float*, int, float*, hipStream_t);
 int gmpc_big_backward(const BigWork&, int, const MlpDesc&, const LinPad&, const uint32_t*, const float*,
                       const float*, const float*, const float*, const float*, const float*, const int*,
-                      float*, float*, float*, float*, hipStream_t);
+                      float*, float*, float*, float*, const float*, float*, hipStream_t);
+int gmpc_big_forward_tangent(const BigWork&, int, const MlpDesc&, const LinPad&, const uint32_t*,
+                             const float*, const float*, float*, float*, hipStream_t);
 void gmpc_launch_big_cont(int, int, int, const float*, const float*, const int*, const float*,
                           const float*, const float*, const float*, const gmpc_ilqr_opts&, const int*,
                           int*, hipStream_t);
@@ -433,7 +435,7 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
       ProfScope ps(c, PROF_RICCATI, s);
       // the gains feed the GEMMs as a padded operand: always build them in the ctx buffer
       if (gmpc_big_backward(c->bw, B, c->dyn, c->lp, c->masks, X, U, goal, c->mpc_w, c->QT, c->qT, active,
-                            c->Ks, k, grad ? grad : c->grads, adj ? adj : c->adjs, s) != 0)
+                            c->Ks, k, grad ? grad : c->grads, adj ? adj : c->adjs, nullptr, nullptr, s) != 0)
         return fail(GMPC_EINVAL, "large-state backward: Jacobian kernel does not cover this shape");
       if (K != c->Ks)
         HIP_TRY(hipMemcpyAsync(K, c->Ks, (size_t)B * sh.T * sh.m * sh.n * sizeof(float),
@@ -837,19 +839,27 @@ extern "C" int gmpc_bilevel_grad(gmpc_ctx* c, int B, int loss_kind, const float*
   TRY(check_call(c, B));
   if (c->solB != B) return fail(GMPC_EINVAL, "gmpc_ilqr_solve with B=%d must precede this call", B);
   if (!loss || !grad_sum) return fail(GMPC_EINVAL, "null argument");
-  if (c->big) return fail(GMPC_EINVAL, "the bilevel gradient for n > 64 is not built yet");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const gmpc_shape& sh = c->sh;
   const int n = sh.n, m = sh.m, T = sh.T;
   TRY(upper_loss(c, B, loss_kind, desired, critic, loss, true, s));
   // a8: Bvec; a9+solve: structured Hessian solve; a11: cost_vjp
-  gmpc_launch_bvec(B, T, n, m, c->AB, c->lx, c->Bvec, s);
-  RiccatiArgs r;
-  memset(&r, 0, sizeof(r));
-  r.B = B; r.n = n; r.m = m; r.T = T; r.mode = 1;
-  r.X = c->Xs; r.U = c->Us; r.goal = c->goals; r.mpc_w = c->mpc_w; r.AB = c->AB; r.QT = c->QT;
-  r.qT = c->qT; r.K = c->Ks; r.k = c->ks; r.Bvec = c->Bvec; r.Hout = c->Hout; r.dX = c->dX;
-  gmpc_launch_riccati(r, s);
+  if (c->big) {
+    // step-major: the loss adjoint (Bvec) and the Riccati sweep of the Hessian solve share one
+    // backward pass over re-linearised steps, the tangent roll is a second, forward pass
+    if (gmpc_big_backward(c->bw, B, c->dyn, c->lp, c->masks, c->Xs, c->Us, c->goals, c->mpc_w, c->QT,
+                          c->qT, nullptr, c->Ks, c->ks, nullptr, nullptr, c->lx, c->Bvec, s) != 0 ||
+        gmpc_big_forward_tangent(c->bw, B, c->dyn, c->lp, c->masks, c->Ks, c->ks, c->Hout, c->dX, s) != 0)
+      return fail(GMPC_EINVAL, "large-state bilevel: Jacobian kernel does not cover this shape");
+  } else {
+    gmpc_launch_bvec(B, T, n, m, c->AB, c->lx, c->Bvec, s);
+    RiccatiArgs r;
+    memset(&r, 0, sizeof(r));
+    r.B = B; r.n = n; r.m = m; r.T = T; r.mode = 1;
+    r.X = c->Xs; r.U = c->Us; r.goal = c->goals; r.mpc_w = c->mpc_w; r.AB = c->AB; r.QT = c->QT;
+    r.qT = c->qT; r.K = c->Ks; r.k = c->ks; r.Bvec = c->Bvec; r.Hout = c->Hout; r.dX = c->dX;
+    gmpc_launch_riccati(r, s);
+  }
   gmpc_launch_costvjp(B, T, n, m, c->cost, c->mpc_w, sign, c->Xs, c->Us, c->goals, c->Hout, c->dX,
                       c->gmpc, c->cact, c->cdel, c->cstride, s);
   // sums over the batch: mpc_w (3 columns of gmpc) and the cost layers

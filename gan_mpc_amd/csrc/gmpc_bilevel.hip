@@ -68,8 +68,10 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_costvjp(int B, int T, int n, i
                                                           const float* goal, const float* Hc,
                                                           const float* dX, float* gmpc /*[B][3]*/,
                                                           float* cact, float* cdel, int stride) {
-  __shared__ float4 bufA[GMPC_THREADS];
-  __shared__ float4 bufB[GMPC_THREADS];
+  // bufA holds the terminal state (n rows, may exceed the 256-wide layers); dynamic LDS
+  extern __shared__ __attribute__((aligned(16))) char smem_cv[];
+  float4* bufA = reinterpret_cast<float4*>(smem_cv);
+  float4* bufB = bufA + (n > GMPC_THREADS ? n : GMPC_THREADS);
   __shared__ float zpos[GMPC_MAX_LAYERS][GMPC_THREADS];
   __shared__ float red[2][GMPC_THREADS / 64];
   __shared__ float yv[2][64];
@@ -103,11 +105,11 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_costvjp(int B, int T, int n, i
   const int fo = cm.dims[Lc + 1];
   float4* in = bufA;
   float4* out = bufB;
-  if (tid < n) {
-    const size_t xi = ((size_t)b * (T + 1) + T) * n + tid;
-    in[tid] = make_float4(X[xi], dX[xi], 0.f, 0.f);
-    cact[(size_t)b * stride + tid] = X[xi];
-    cact[(size_t)(B + b) * stride + tid] = dX[xi];
+  for (int i = tid; i < n; i += blockDim.x) {
+    const size_t xi = ((size_t)b * (T + 1) + T) * n + i;
+    in[i] = make_float4(X[xi], dX[xi], 0.f, 0.f);
+    cact[(size_t)b * stride + i] = X[xi];
+    cact[(size_t)(B + b) * stride + i] = dX[xi];
   }
   __syncthreads();
   int aoff = n;
@@ -192,6 +194,7 @@ void gmpc_launch_costvjp(int B, int T, int n, int m, const MlpDesc& cm, const fl
                          float sign, const float* X, const float* U, const float* goal,
                          const float* Hc, const float* dX, float* gmpc, float* cact, float* cdel,
                          int stride, hipStream_t s) {
-  hipLaunchKernelGGL(k_costvjp, dim3(B), dim3(GMPC_THREADS), 0, s, B, T, n, m, cm, mpc_w, sign, X, U,
+  const size_t lds = ((size_t)(n > GMPC_THREADS ? n : GMPC_THREADS) + GMPC_THREADS) * sizeof(float4);
+  hipLaunchKernelGGL(k_costvjp, dim3(B), dim3(GMPC_THREADS), lds, s, B, T, n, m, cm, mpc_w, sign, X, U,
                      goal, Hc, dX, gmpc, cact, cdel, stride);
 }

@@ -241,6 +241,11 @@ void gmpc_launch_bgemm_tn(const BgemmArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 struct BigStepArgs {
   int B, n, m, T, t;
+  int mode;              // 0: iLQR step (trajax lqr_step, Cholesky of G + 1e-8 I)
+                         // 1: bilevel Hessian solve (oracle hessian_solve: no regulariser, LU with
+                         //    partial pivoting, linear term -Bvec_t, loss adjoint mu in `lam`)
+  const float* lx;       // mode 1: [B][T+1][n] d loss / d X
+  float* Bvec;           // mode 1: [B][T][m]   out: B_t^T mu_{t+1}
   const float* X; const float* U; const float* goal; const float* mpc_w;
   const float* ABt;      // [B][n][n+m]   Jacobians of step t
   const float* HG;       // [B][m][n+m]   [B^T P A | B^T P B]
@@ -253,7 +258,7 @@ struct BigStepArgs {
 };
 
 static size_t big_step_lds(int n, int m) {
-  return ((size_t)2 * m * m + 5 * (size_t)n + 6 * (size_t)m + 16 + 2 * GMPC_THREADS +
+  return ((size_t)2 * m * m + 5 * (size_t)n + 7 * (size_t)m + 16 + 2 * GMPC_THREADS +
           (size_t)m * GMPC_THREADS) * sizeof(float);
 }
 
@@ -275,7 +280,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   float* kv = hv + m;                            // m
   float* gk = kv + m;                            // m   G k + h
   float* gsq = gk + m;                           // m
-  float* red = gsq + m;                          // 16
+  int* perm = reinterpret_cast<int*>(gsq + m);   // m   row permutation of the LU (mode 1)
+  float* red = gsq + 2 * m;                      // 16
   float* part = red + 16;                        // 2 x 256 partial sums
   float* ycol = part + 2 * GMPC_THREADS;         // m x 256: one solve column per thread
   const float* AB = a.ABt + (size_t)b * n * nm;
@@ -305,8 +311,13 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   const float s = sqrtf(dd + al * al), su = sqrtf(uu + al * al);
   const float isu = 1.f / su, isu3 = 1.f / (su * su * su);
   if (tid == 0) a.sbuf[b] = s;
-  for (int i = tid; i < n; i += blockDim.x) qv[i] = w1 * dv[i] / s;
-  for (int j = tid; j < m; j += blockDim.x) rv[j] = w0 * uv[j] / su;
+  // linear terms of the two vector recursions: mode 0 the cost gradient (q_t, r_t) for both the
+  // adjoint lambda and the value vector p; mode 1 (d loss/d x_t, 0) for the loss adjoint and (0, -Bvec_t)
+  // for p
+  const bool m1 = a.mode == 1;
+  for (int i = tid; i < n; i += blockDim.x)
+    qv[i] = m1 ? a.lx[((size_t)b * (T + 1) + t) * n + i] : w1 * dv[i] / s;
+  for (int j = tid; j < m; j += blockDim.x) rv[j] = m1 ? 0.f : w0 * uv[j] / su;
   __syncthreads();
   // g_t = r + B^T lam ; h = r + B^T p : thread (rp, j) sums rows rp, rp + RP, ... of column j of B
   {
@@ -326,8 +337,13 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
       float gs = 0.f, hs = 0.f;
       for (int r = 0; r < RP; ++r) { gs += part[r * MC + tid]; hs += part[GMPC_THREADS + r * MC + tid]; }
       gs = rv[tid] + gs;
-      hv[tid] = rv[tid] + hs;
-      a.grad[bt * m + tid] = gs;
+      if (m1) {
+        a.Bvec[bt * m + tid] = gs;          // B_t^T mu_{t+1}
+        hv[tid] = hs - gs;                  // h = -Bvec_t + B^T p
+      } else {
+        hv[tid] = rv[tid] + hs;
+        a.grad[bt * m + tid] = gs;
+      }
       gsq[tid] = gs * gs;
     }
   }
@@ -342,7 +358,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     pa[c] = vp;
     const float ln = qv[c] + vl;
     a.lam[(size_t)b * n + c] = ln;
-    a.adj[((size_t)b * (T + 1) + t) * n + c] = ln;
+    if (!m1) a.adj[((size_t)b * (T + 1) + t) * n + c] = ln;
   }
   // G = sym(R + B^T P B)
   for (int e = tid; e < m * m; e += blockDim.x) {
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     L[e] = Rij + HG[(size_t)i * nm + n + j];
   }
   __syncthreads();
-  if (tid == 0) {
+  if (tid == 0 && !m1) {
     float sg = 0.f;
     for (int j = 0; j < m; ++j) sg += gsq[j];
     a.gn2[b] += sg;
@@ -361,49 +377,104 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     G[e] = (L[e] + L[j * m + i]) * 0.5f;
   }
   __syncthreads();
-  // Cholesky of G + 1e-8 I in L (lower), column by column; NaN on a non-positive pivot
-  for (int e = tid; e < m * m; e += blockDim.x) L[e] = G[e] + ((e / m) == (e % m) ? 1e-8f : 0.f);
-  __syncthreads();
-  for (int j = 0; j < m; ++j) {
-    if (tid == 0) L[j * m + j] = sqrtf(L[j * m + j]);
-    __syncthreads();
-    const float d = L[j * m + j];
-    for (int i = j + 1 + tid; i < m; i += blockDim.x) L[i * m + j] /= d;
-    __syncthreads();
-    // trailing update of the lower triangle: L[i][k] -= L[i][j] L[k][j], j < k <= i
-    const int rem = m - j - 1;
-    for (int e = tid; e < rem * rem; e += blockDim.x) {
-      const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-      if (k <= i) L[i * m + k] -= L[i * m + j] * L[k * m + j];
-    }
-    __syncthreads();
-  }
-  // [K k] = -(G + delta I)^-1 [H h], one right-hand-side column per thread (column n is h); the
-  // thread keeps its column in LDS (ycol[i][tid]) and also emits W = H + (H + G K) for it
   float* Kt = a.K + bt * m * n;
   float* W = a.W + (size_t)b * m * n;
   float* y = ycol + tid;
-  for (int c = tid; c <= n; c += blockDim.x) {
-    for (int i = 0; i < m; ++i) {
-      float v = c < n ? HG[(size_t)i * nm + c] : hv[i];
-      for (int k = 0; k < i; ++k) v -= L[i * m + k] * y[k * GMPC_THREADS];
-      y[i * GMPC_THREADS] = v / L[i * m + i];
-    }
-    for (int i = m - 1; i >= 0; --i) {
-      float v = y[i * GMPC_THREADS];
-      for (int k = i + 1; k < m; ++k) v -= L[k * m + i] * y[k * GMPC_THREADS];
-      y[i * GMPC_THREADS] = v / L[i * m + i];
-    }
-    if (c < n) {
-      for (int i = 0; i < m; ++i) Kt[(size_t)i * n + c] = -y[i * GMPC_THREADS];
-      for (int i = 0; i < m; ++i) {
-        float v = 0.f;
-        for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], -y[k * GMPC_THREADS], v);
-        const float hic = HG[(size_t)i * nm + c];
-        W[(size_t)i * n + c] = hic + (hic + v);
+  if (!m1) {
+    // Cholesky of G + 1e-8 I in L (lower), column by column; NaN on a non-positive pivot
+    for (int e = tid; e < m * m; e += blockDim.x) L[e] = G[e] + ((e / m) == (e % m) ? 1e-8f : 0.f);
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+      if (tid == 0) L[j * m + j] = sqrtf(L[j * m + j]);
+      __syncthreads();
+      const float d = L[j * m + j];
+      for (int i = j + 1 + tid; i < m; i += blockDim.x) L[i * m + j] /= d;
+      __syncthreads();
+      // trailing update of the lower triangle: L[i][k] -= L[i][j] L[k][j], j < k <= i
+      const int rem = m - j - 1;
+      for (int e = tid; e < rem * rem; e += blockDim.x) {
+        const int i = j + 1 + e / rem, k = j + 1 + e % rem;
+        if (k <= i) L[i * m + k] -= L[i * m + j] * L[k * m + j];
       }
-    } else {
-      for (int i = 0; i < m; ++i) { kv[i] = -y[i * GMPC_THREADS]; a.k[bt * m + i] = -y[i * GMPC_THREADS]; }
+      __syncthreads();
+    }
+    // [K k] = -(G + delta I)^-1 [H h], one right-hand-side column per thread (column n is h); the
+    // thread keeps its column in LDS (ycol[i][tid])
+    for (int c = tid; c <= n; c += blockDim.x) {
+      for (int i = 0; i < m; ++i) {
+        float v = c < n ? HG[(size_t)i * nm + c] : hv[i];
+        for (int k = 0; k < i; ++k) v -= L[i * m + k] * y[k * GMPC_THREADS];
+        y[i * GMPC_THREADS] = v / L[i * m + i];
+      }
+      for (int i = m - 1; i >= 0; --i) {
+        float v = y[i * GMPC_THREADS];
+        for (int k = i + 1; k < m; ++k) v -= L[k * m + i] * y[k * GMPC_THREADS];
+        y[i * GMPC_THREADS] = v / L[i * m + i];
+      }
+      if (c < n) {
+        for (int i = 0; i < m; ++i) Kt[(size_t)i * n + c] = -y[i * GMPC_THREADS];
+      } else {
+        for (int i = 0; i < m; ++i) { kv[i] = -y[i * GMPC_THREADS]; a.k[bt * m + i] = -y[i * GMPC_THREADS]; }
+      }
+    }
+  } else {
+    // LU with partial pivoting (jax.scipy.linalg.solve as the reference calls it), in place in L:
+    // unit-lower multipliers below the diagonal, U on and above; perm = row order
+    for (int e = tid; e < m * m; e += blockDim.x) L[e] = G[e];
+    for (int i = tid; i < m; i += blockDim.x) perm[i] = i;
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+      if (tid == 0) {
+        int piv = j;
+        float best = fabsf(L[j * m + j]);
+        for (int i = j + 1; i < m; ++i)
+          if (fabsf(L[i * m + j]) > best) { best = fabsf(L[i * m + j]); piv = i; }
+        red[0] = (float)piv;
+        if (piv != j) { const int tp = perm[j]; perm[j] = perm[piv]; perm[piv] = tp; }
+      }
+      __syncthreads();
+      const int piv = (int)red[0];
+      if (piv != j)
+        for (int c = tid; c < m; c += blockDim.x) {
+          const float tv_ = L[j * m + c]; L[j * m + c] = L[piv * m + c]; L[piv * m + c] = tv_;
+        }
+      __syncthreads();
+      const float d = L[j * m + j];
+      for (int i = j + 1 + tid; i < m; i += blockDim.x) L[i * m + j] /= d;
+      __syncthreads();
+      const int rem = m - j - 1;
+      for (int e = tid; e < rem * rem; e += blockDim.x) {
+        const int i = j + 1 + e / rem, k = j + 1 + e % rem;
+        L[i * m + k] -= L[i * m + j] * L[j * m + k];
+      }
+      __syncthreads();
+    }
+    for (int c = tid; c <= n; c += blockDim.x) {
+      for (int i = 0; i < m; ++i) {
+        const int pi = perm[i];
+        float v = c < n ? HG[(size_t)pi * nm + c] : hv[pi];
+        for (int k = 0; k < i; ++k) v -= L[i * m + k] * y[k * GMPC_THREADS];
+        y[i * GMPC_THREADS] = v;
+      }
+      for (int i = m - 1; i >= 0; --i) {
+        float v = y[i * GMPC_THREADS];
+        for (int k = i + 1; k < m; ++k) v -= L[i * m + k] * y[k * GMPC_THREADS];
+        y[i * GMPC_THREADS] = v / L[i * m + i];
+      }
+      if (c < n) {
+        for (int i = 0; i < m; ++i) Kt[(size_t)i * n + c] = -y[i * GMPC_THREADS];
+      } else {
+        for (int i = 0; i < m; ++i) { kv[i] = -y[i * GMPC_THREADS]; a.k[bt * m + i] = -y[i * GMPC_THREADS]; }
+      }
+    }
+  }
+  // W = H + (H + G K) for the thread's own columns (K column read back from its own writes)
+  for (int c = tid; c < n; c += blockDim.x) {
+    for (int i = 0; i < m; ++i) {
+      float v = 0.f;
+      for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], Kt[(size_t)k * n + c], v);
+      const float hic = HG[(size_t)i * nm + c];
+      W[(size_t)i * n + c] = hic + (hic + v);
     }
   }
   __syncthreads();
@@ -420,7 +491,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
       v1 = fmaf(HG[(size_t)i * nm + c], kv[i], v1);
       v2 = fmaf(Kt[(size_t)i * n + c], gk[i], v2);   // own column: written by this thread above
     }
-    a.pvec[(size_t)b * n + c] = ((qv[c] + pa[c]) + v1) + v2;
+    a.pvec[(size_t)b * n + c] = (((m1 ? 0.f : qv[c]) + pa[c]) + v1) + v2;
   }
 }
 
@@ -473,16 +544,21 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_pupdate(int n, int T, int 
 }
 
 __global__ void k_big_init(int B, int n, int T, const float* QT, const float* qT, const int* active,
-                           float* P, float* pvec, float* lam, float* adj, float* gn2) {
+                           float* P, float* pvec, float* lam, float* adj, float* gn2, const float* lx) {
   const int b = blockIdx.y;
   if (active != nullptr && active[b] == 0) return;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < n * n) P[(size_t)b * n * n + e] = QT[(size_t)b * n * n + e];
   if (e < n) {
-    const float q = qT[(size_t)b * n + e];
-    pvec[(size_t)b * n + e] = q;
-    lam[(size_t)b * n + e] = q;
-    adj[((size_t)b * (T + 1) + T) * n + e] = q;
+    if (lx == nullptr) {
+      const float q = qT[(size_t)b * n + e];
+      pvec[(size_t)b * n + e] = q;
+      lam[(size_t)b * n + e] = q;
+      adj[((size_t)b * (T + 1) + T) * n + e] = q;
+    } else {          // bilevel solve: value vector 0, loss adjoint d loss / d x_T
+      pvec[(size_t)b * n + e] = 0.f;
+      lam[(size_t)b * n + e] = lx[((size_t)b * (T + 1) + T) * n + e];
+    }
   }
   if (e == 0) gn2[b] = 0.f;
 }
@@ -516,11 +592,12 @@ int gmpc_launch_linearize_mfma(int NSamp, int T, int n, int m, const MlpDesc& dy
 int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad& lp,
                       const uint32_t* masks, const float* X, const float* U, const float* goal,
                       const float* mpc_w, const float* QT, const float* qT, const int* active, float* K,
-                      float* k, float* grad, float* adj, hipStream_t s) {
+                      float* k, float* grad, float* adj, const float* lx, float* Bvec, hipStream_t s) {
+  // lx != null: the bilevel Hessian solve (k_big_step mode 1); grad / adj are not written then
   const int n = w.n, m = w.m, T = w.T, nm = n + m;
   const dim3 ge((n * n + 255) / 256, B);
   hipLaunchKernelGGL(k_big_init, ge, dim3(256), 0, s, B, n, T, QT, qT, active, w.P, w.pvec, w.lam, adj,
-                     w.gn2);
+                     w.gn2, lx);
   const size_t lds = big_step_lds(n, m);
   if (lds > 128 * 1024) return -2;
   static bool attr = false;
@@ -551,6 +628,7 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
     gmpc_launch_bgemm_tn(gemm(m, nm, n, Bm, snm, nm, w.PAB, snm, nm, w.HG, smnm, nm), s);
     BigStepArgs a;
     a.B = B; a.n = n; a.m = m; a.T = T; a.t = t;
+    a.mode = lx != nullptr ? 1 : 0; a.lx = lx; a.Bvec = Bvec;
     a.X = X; a.U = U; a.goal = goal; a.mpc_w = mpc_w; a.ABt = w.ABt; a.HG = w.HG; a.W = w.W;
     a.pvec = w.pvec; a.lam = w.lam; a.sbuf = w.sbuf; a.gn2 = w.gn2; a.active = active;
     a.K = K; a.k = k; a.grad = grad; a.adj = adj;
@@ -562,6 +640,53 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
     gmpc_launch_bgemm_tn(g, s);
     hipLaunchKernelGGL(k_big_pupdate, dim3(nt, nt, B), dim3(GMPC_THREADS), 0, s, n, T, t, X, goal, mpc_w,
                        w.sbuf, w.T1, active, w.P);
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward tangent roll of the bilevel solve: dU_t = k_t + K_t dX_t ; dX_{t+1} = A_t dX_t + B_t dU_t
+// (oracle hessian_solve, second loop).  One workgroup per trajectory and time step; [A|B] of the step
+// comes from the same strided Jacobian chain as in the backward pass.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GMPC_THREADS) void k_big_fwd(int n, int m, int T, int t, const float* ABt,
+                                                          const float* K, const float* k, float* Hout,
+                                                          float* dX) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* dx = reinterpret_cast<float*>(smem);   // n
+  float* du = dx + n;                           // m
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nm = n + m;
+  const size_t bt = (size_t)b * T + t;
+  for (int i = tid; i < n; i += blockDim.x) dx[i] = t == 0 ? 0.f : dX[((size_t)b * (T + 1) + t) * n + i];
+  __syncthreads();
+  for (int j = wave; j < m; j += GMPC_THREADS / 64) {
+    const float* Kr = K + (bt * m + j) * n;
+    float v = 0.f;
+    for (int i = lane; i < n; i += 64) v = fmaf(Kr[i], dx[i], v);
+    v = wave_sum(v);
+    if (lane == 0) { const float u = k[bt * m + j] + v; du[j] = u; Hout[bt * m + j] = u; }
+  }
+  if (t == 0)
+    for (int i = tid; i < n; i += blockDim.x) dX[(size_t)b * (T + 1) * n + i] = 0.f;
+  __syncthreads();
+  const float* AB = ABt + (size_t)b * n * nm;
+  for (int i = wave; i < n; i += GMPC_THREADS / 64) {
+    const float* row = AB + (size_t)i * nm;
+    float v = 0.f;
+    for (int c = lane; c < nm; c += 64) v = fmaf(row[c], c < n ? dx[c] : du[c - n], v);
+    v = wave_sum(v);
+    if (lane == 0) dX[((size_t)b * (T + 1) + t + 1) * n + i] = v;
+  }
+}
+
+int gmpc_big_forward_tangent(const BigWork& w, int B, const MlpDesc& dyn, const LinPad& lp,
+                             const uint32_t* masks, const float* K, const float* k, float* Hout, float* dX,
+                             hipStream_t s) {
+  const int n = w.n, m = w.m, T = w.T;
+  for (int t = 0; t < T; ++t) {
+    if (gmpc_launch_linearize_mfma(B, T, n, m, dyn, lp, masks, nullptr, w.ABt, T, t, s) != 0) return -1;
+    hipLaunchKernelGGL(k_big_fwd, dim3(B), dim3(GMPC_THREADS), (size_t)(n + m) * sizeof(float), s, n, m, T,
+                       t, w.ABt, K, k, Hout, dX);
   }
   return 0;
 }

@@ -198,12 +198,13 @@ def test_ilqr_converges_on_lq_problem():
     assert gu.rel_err(obj, c64) < 1e-5
 
 
-@pytest.mark.parametrize("loss_kind", [0, 1])
-def test_bilevel_grad(loss_kind):
+@pytest.mark.parametrize("name,loss_kind", [("trained-like", 0), ("trained-like", 1), ("big-70", 0),
+                                            ("big-70", 1), ("c4-humanoid", 0)])
+def test_bilevel_grad(name, loss_kind):
     """a8-a11 at the lower-level solution the GPU found.  The Hessian solve is ill-conditioned
     (forward error = cond(A) x backward error), so H is checked by its residual A H - B in fp64;
     the remaining stages are checked stage-by-stage with the GPU's own H, dX as input."""
-    pb, pb64, eng = _setup("trained-like", critic=True)
+    pb, pb64, eng = _setup(name, critic=True)
     d = eng.to_dev
     T, n, m = pb["T"], pb["n"], pb["m"]
     out = eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]), {"maxiter": 3})
@@ -215,7 +216,7 @@ def test_bilevel_grad(loss_kind):
     q = np.concatenate([Xf[:, :T], Uf.astype(np.float64)], -1).reshape(-1, n + m)
     bad = gu.near_kink(pb64["dyn"], q).reshape(-1, T).any(1) | gu.near_kink(pb64["cmlp"], Xf[:, T])
     ok = ~bad
-    assert ok.sum() >= pb["B"] // 2
+    assert ok.sum() >= max(1, pb["B"] // 2)
     for p_ in (pb, pb64):
         for key in ("x0", "goal", "true_seq"):
             p_[key] = p_[key][ok]
