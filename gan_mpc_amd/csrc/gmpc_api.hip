@@ -19,6 +19,8 @@ void gmpc_launch_masks(int, int, int, int, const MlpDesc&, const float*, const f
                        hipStream_t);
 int gmpc_launch_linearize(int, int, int, int, const MlpDesc&, const uint32_t*, const int*, float*,
                           hipStream_t);
+int gmpc_launch_linearize_regs(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
+                               const int*, float*, int, int, hipStream_t);
 int gmpc_launch_linearize_mfma(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
                                const int*, float*, int, int, hipStream_t);
 void gmpc_launch_bgemm_tn(const BgemmArgs&, hipStream_t);
@@ -451,11 +453,15 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     ProfScope ps(c, PROF_LINEARIZE, s);
     // matrix-core chain; the VALU chain only serves shapes the MFMA tiling does not cover (or
     // GMPC_LINEARIZE=valu, kept for A/B timing) -- both are HIP kernels of this library
-    static const bool force_valu = []() {
+    static const int force = []() {
       const char* e = getenv("GMPC_LINEARIZE");
-      return e && strcmp(e, "valu") == 0;
+      return !e ? 0 : strcmp(e, "valu") == 0 ? 2 : strcmp(e, "lds") == 0 ? 1 : 0;
     }();
-    if (force_valu ||
+    // 1st choice: register-resident chain (compiled for the common equal-width shapes), 2nd: the
+    // LDS-operand chain (any shape), 3rd: VALU
+    if (force == 0 && gmpc_launch_linearize_regs(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active,
+                                                 AB, 1, 0, s) == 0) {
+    } else if (force == 2 ||
         gmpc_launch_linearize_mfma(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active, AB, 1, 0,
                                    s) != 0) {
       if (gmpc_launch_linearize(B, sh.T, sh.n, sh.m, c->dyn, c->masks, active, AB, s) != 0)

@@ -1,0 +1,188 @@
+// Dynamics Jacobian chain on the matrix cores, register-resident variant (gfx950 only).
+//
+// Same product as gmpc_linearize_mfma.hip -- [A_t | B_t] - [I | 0] = W_L^T D_{L-1} W_{L-1}^T ... D_1 W_1^T
+// for the stacked Jacobian rows of all samples -- but transposed: the stacked rows are the COLUMNS
+// of the MFMA tiles (one per lane), the weights are the A operand and the running product S_l
+// (hidden x 32 rows) never leaves the register file:
+//   S_{L-1}[k][r] = W_L[k][i_r] * relu bit(sample_r, k)                                  (seed)
+//   S_{l-1}       = D_{l-1} (W_l S_l)        l = L-1 .. 2       (NT x KS MFMAs per tile and layer)
+//   out           = W_1 S_1                                     (KS MFMAs)
+// An accumulator tile holds (rows = hidden unit, lanes = stacked row); the next GEMM wants it as B
+// operand (lane halves = two consecutive k rows).  v_permlane32_swap_b32 (new on gfx950) exchanges
+// the upper half of one register with the lower half of its neighbour, which is exactly that
+// re-pairing: 8 swaps turn a 16-register accumulator tile into 16 B operands, so the chain needs no
+// LDS round trip, no relu select in the k-loop (the bits are applied once per accumulator) and no
+// barrier.  Per k-step a wave issues two 16-byte weight loads (lane-interleaved copies shared with
+// the LDS variant) and NT MFMAs.  Measured: 69.5 cycles per 32x32x2 issue for this inner loop against
+// 72.9 (micro-benchmark) / 82 (in the kernel) for the LDS-operand variant.
+//
+// Compile-time shape: NT row tiles (hidden width <= 32 NT) and KS k-steps (hidden width = 2 KS or
+// 2 KS - 1), all hidden layers of the same width, n + m <= 32.  Everything else runs the LDS variant.
+#include "gmpc_device.h"
+
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+#define GMPC_LIN_PADROWS 24
+
+__device__ __forceinline__ void swap_halves(float& a, float& b) {
+  // a = (a.lower | b.lower), b = (a.upper | b.upper)
+  const v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x);
+  b = __uint_as_float(r.y);
+}
+
+template <int NT, int KS>
+__global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
+    int NSamp, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
+    float* AB, int ntiles, int samp_mul, int samp_add) {
+  static_assert(NT <= 8 && 2 * KS <= 32 * NT, "shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* wl_s = reinterpret_cast<float*>(smem);          // W_L  [(H + pad)][n]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int Lh = dyn.L - 1, nm = n + m;
+  const int Rtot = NSamp * n;
+  const int wl_floats = (dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;
+  for (int e = threadIdx.x; e < wl_floats; e += blockDim.x) wl_s[e] = lp.WLP[e];
+  __syncthreads();   // the only workgroup barrier
+
+  for (int tile = blockIdx.x * (GMPC_THREADS / 64) + wave; tile < ntiles;
+       tile += gridDim.x * (GMPC_THREADS / 64)) {
+    const int r0 = tile * 32;
+    int R = r0 + l31;                          // this lane's stacked Jacobian row
+    const bool rvalid = R < Rtot;
+    if (!rvalid) R = Rtot - 1;                 // clamped reads, no writes
+    const int s = R / n, irow = R - s * n;
+    const size_t sid = (size_t)s * samp_mul + samp_add;
+    if (active != nullptr) {
+      const bool on = active[sid / T] != 0;
+      if (__ballot(on && rvalid) == 0ull) continue;
+    }
+    const uint32_t* mrow = masks + sid * Lh * GMPC_MW;
+
+    // ---- seed: S[ks] = W_L[2 ks + half][irow] * relu bit of hidden layer Lh-1
+    float S[16 * NT];
+    {
+      uint32_t mw[NT];
+#pragma unroll
+      for (int w = 0; w < NT; ++w) mw[w] = mrow[(Lh - 1) * GMPC_MW + w] >> half;
+      const float* wl = wl_s + half * n + irow;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float v = wl[2 * ks * n];
+        S[ks] = ((mw[(2 * ks) >> 5] >> ((2 * ks) & 31)) & 1u) ? v : 0.f;
+      }
+    }
+
+    // ---- hidden GEMMs  S_{l-1} = D_{l-1} (W_l S_l),  l = Lh-1 .. 1
+    for (int l = Lh - 1; l >= 1; --l) {
+      f32x16 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
+      const float4* __restrict__ bp =
+          reinterpret_cast<const float4*>(lp.WTP[l]) + half * 64 + l31 * 2;
+      float4 w[3][2];
+      w[0][0] = bp[0]; w[0][1] = bp[1];
+      w[1][0] = bp[128]; w[1][1] = bp[129];
+      // relu words of the layer this GEMM produces (loaded early, used in the epilogue)
+      uint32_t mw[NT];
+#pragma unroll
+      for (int t_ = 0; t_ < NT; ++t_) mw[t_] = mrow[(l - 1) * GMPC_MW + t_] >> (4 * half);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 2 < KS) {
+          w[(ks + 2) % 3][0] = bp[(ks + 2) * 128];
+          w[(ks + 2) % 3][1] = bp[(ks + 2) * 128 + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float b = S[ks];
+        const float4 q0 = w[ks % 3][0], q1 = w[ks % 3][1];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.x, b, acc[0], 0, 0, 0);
+        if (NT > 1) acc[1 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.y, b, acc[1 % NT], 0, 0, 0);
+        if (NT > 2) acc[2 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.z, b, acc[2 % NT], 0, 0, 0);
+        if (NT > 3) acc[3 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.w, b, acc[3 % NT], 0, 0, 0);
+        if (NT > 4) acc[4 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.x, b, acc[4 % NT], 0, 0, 0);
+        if (NT > 5) acc[5 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.y, b, acc[5 % NT], 0, 0, 0);
+        if (NT > 6) acc[6 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.z, b, acc[6 % NT], 0, 0, 0);
+        if (NT > 7) acc[7 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.w, b, acc[7 % NT], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // epilogue: relu bits of hidden layer l-1 (rows of acc), then re-pair rows into B operands
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int rg = 0; rg < 16; rg += 2) {
+          const int rho = (rg & 3) + 8 * (rg >> 2);              // row of the lower lanes of reg rg
+          float a0 = ((mw[nt] >> rho) & 1u) ? acc[nt][rg] : 0.f;
+          float a1 = ((mw[nt] >> (rho + 1)) & 1u) ? acc[nt][rg + 1] : 0.f;
+          swap_halves(a0, a1);      // a0: rows (rho, rho+1); a1: rows (rho+4, rho+5)
+          S[(nt * 32 + rho) / 2] = a0;
+          S[(nt * 32 + rho + 4) / 2] = a1;
+        }
+      }
+    }
+
+    // ---- input GEMM  out = W_1 S_1 : rows = input coordinate c (n + m <= 32), one MFMA per k-step
+    f32x16 acc0;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) acc0[rg] = 0.f;
+    {
+      const float* __restrict__ ap = lp.WTP[0] + half * 32 + l31;
+      float a[6];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) a[j] = ap[j * 64];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 5 < KS) a[(ks + 5) % 6] = ap[(ks + 5) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks % 6], S[ks], acc0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (rvalid) {
+      float* dst = AB + (size_t)R * nm;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int c = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+        if (c < nm) dst[c] = acc0[rg] + (c == irow ? 1.0f : 0.0f);
+      }
+    }
+  }
+}
+
+template <int NT, int KS>
+static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
+                       const uint32_t* masks, const int* active, float* AB, int samp_mul, int samp_add,
+                       hipStream_t s) {
+  const long Rtot = (long)NSamp * n;
+  if (Rtot >= (1L << 31) - 64) return -1;
+  const int ntiles = (int)((Rtot + 31) / 32);
+  const int Lh = dyn.L - 1;
+  const size_t lds = (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n * sizeof(float);
+  if (lds > 64 * 1024) return -1;
+  int grid = (ntiles + 3) / 4;
+  if (grid > 256) grid = 256;   // one persistent workgroup per CU (one wave per SIMD: 512 registers)
+  hipLaunchKernelGGL((k_linearize_regs<NT, KS>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
+                     dyn, lp, masks, active, AB, ntiles, samp_mul, samp_add);
+  return 0;
+}
+
+// returns 0 on launch, -1 when the shape is not one this variant is compiled for
+int gmpc_launch_linearize_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
+                               const uint32_t* masks, const int* active, float* AB, int samp_mul,
+                               int samp_add, hipStream_t s) {
+  const int Lh = dyn.L - 1;
+  if (Lh < 2 || n + m > 32 || lp.NTF != 1 || lp.NGF != 1) return -1;
+  const int H = dyn.dims[1];
+  for (int l = 1; l <= Lh; ++l)
+    if (dyn.dims[l] != H) return -1;
+  if (H == 200 && lp.NT == 7)
+    return launch_regs<7, 100>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
+  if (H == 128 && lp.NT == 4)
+    return launch_regs<4, 64>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
+  if (H == 64 && lp.NT == 2)
+    return launch_regs<2, 32>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
+  return -1;
+}

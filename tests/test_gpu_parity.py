@@ -20,6 +20,9 @@ SHAPES = {
     "c2-cheetah": (17, 6, 50, 48, {}),
     "trained-like": (17, 6, 50, 32, dict(out_scale=0.1)),
     "wide": (40, 9, 6, 5, dict(dyn_hidden=(256, 64), cost_hidden=(256, 100), cost_fout=32)),
+    # equal-width hidden layers of 128 / 64: the other instantiations of the register-resident chain
+    "regs-128": (9, 3, 7, 11, dict(dyn_hidden=(128, 128), cost_hidden=(32,), cost_fout=4)),
+    "regs-64": (6, 2, 5, 9, dict(dyn_hidden=(64, 64, 64), cost_hidden=(16,), cost_fout=3)),
     # n > 64: the step-major large-state backward pass (gmpc_large.hip)
     "big-70": (70, 7, 6, 5, dict(dyn_hidden=(128, 96), cost_hidden=(64,), cost_fout=12, out_scale=0.3)),
     "c4-humanoid": (376, 17, 4, 3, dict(out_scale=0.3)),
