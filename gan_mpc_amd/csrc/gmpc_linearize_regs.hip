@@ -23,6 +23,9 @@
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 #define GMPC_LIN_PADROWS 24
+#ifndef GMPC_REGS_RING
+#define GMPC_REGS_RING 3
+#endif
 
 __device__ __forceinline__ void swap_halves(float& a, float& b) {
   // a = (a.lower | b.lower), b = (a.upper | b.upper)
@@ -45,6 +48,11 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
   const int wl_floats = (dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;
   for (int e = threadIdx.x; e < wl_floats; e += blockDim.x) wl_s[e] = lp.WLP[e];
   __syncthreads();   // the only workgroup barrier
+  // diagnostic stamps (GMPC_LIN_STAMPS=1): 0 seed, 1 hidden GEMMs, 2 epilogues, 3 input GEMM, 4 stores
+  unsigned long long st[5] = {0, 0, 0, 0, 0}, tprev = 0;
+  const bool stamps = lp.dbg != nullptr;
+#define GMPC_STAMP(i) if (stamps) { const unsigned long long t_ = __builtin_readcyclecounter(); st[i] += t_ - tprev; tprev = t_; }
+  if (stamps) tprev = __builtin_readcyclecounter();
 
   for (int tile = blockIdx.x * (GMPC_THREADS / 64) + wave; tile < ntiles;
        tile += gridDim.x * (GMPC_THREADS / 64)) {
@@ -74,6 +82,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
       }
     }
 
+    GMPC_STAMP(0)
     // ---- hidden GEMMs  S_{l-1} = D_{l-1} (W_l S_l),  l = Lh-1 .. 1
     for (int l = Lh - 1; l >= 1; --l) {
       f32x16 acc[NT];
@@ -83,22 +92,22 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
         for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
       const float4* __restrict__ bp =
           reinterpret_cast<const float4*>(lp.WTP[l]) + half * 64 + l31 * 2;
-      float4 w[3][2];
-      w[0][0] = bp[0]; w[0][1] = bp[1];
-      w[1][0] = bp[128]; w[1][1] = bp[129];
+      constexpr int RD = GMPC_REGS_RING;      // operand ring: RD - 1 k-steps of weight loads in flight
+      float4 w[RD][2];
+#pragma unroll
+      for (int j = 0; j < RD - 1; ++j) { w[j][0] = bp[j * 128]; w[j][1] = bp[j * 128 + 1]; }
       // relu words of the layer this GEMM produces (loaded early, used in the epilogue)
       uint32_t mw[NT];
 #pragma unroll
       for (int t_ = 0; t_ < NT; ++t_) mw[t_] = mrow[(l - 1) * GMPC_MW + t_] >> (4 * half);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 2 < KS) {
-          w[(ks + 2) % 3][0] = bp[(ks + 2) * 128];
-          w[(ks + 2) % 3][1] = bp[(ks + 2) * 128 + 1];
+        if (ks + RD - 1 < KS) {
+          w[(ks + RD - 1) % RD][0] = bp[(ks + RD - 1) * 128];
+          w[(ks + RD - 1) % RD][1] = bp[(ks + RD - 1) * 128 + 1];
         }
-        __builtin_amdgcn_sched_barrier(0);
         const float b = S[ks];
-        const float4 q0 = w[ks % 3][0], q1 = w[ks % 3][1];
+        const float4 q0 = w[ks % RD][0], q1 = w[ks % RD][1];
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.x, b, acc[0], 0, 0, 0);
         if (NT > 1) acc[1 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.y, b, acc[1 % NT], 0, 0, 0);
         if (NT > 2) acc[2 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q0.z, b, acc[2 % NT], 0, 0, 0);
@@ -107,8 +116,23 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
         if (NT > 5) acc[5 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.y, b, acc[5 % NT], 0, 0, 0);
         if (NT > 6) acc[6 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.z, b, acc[6 % NT], 0, 0, 0);
         if (NT > 7) acc[7 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.w, b, acc[7 % NT], 0, 0, 0);
+        // spread the two weight loads and their address arithmetic BETWEEN the MFMAs of the k-step:
+        // issued as a block at the k-step boundary they do not overlap the matrix pipe (one wave per
+        // SIMD), see gemm_tile_x4
+        // (only for NT >= 4: with two MFMAs per k-step hipcc 7.2 emits wrong code for this
+        // pattern -- the NT = 2 instantiation failed its parity test, so it keeps plain program order)
+        if (NT >= 4) {
+#pragma unroll
+          for (int i_ = 0; i_ < NT; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // <= 1 VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // <= 2 VALU
+            __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);   // <= 2 SALU
+          }
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
+      GMPC_STAMP(1)
       // epilogue: relu bits of hidden layer l-1 (rows of acc), then re-pair rows into B operands
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -122,6 +146,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
           S[(nt * 32 + rho + 4) / 2] = a1;
         }
       }
+      GMPC_STAMP(2)
     }
 
     // ---- input GEMM  out = W_1 S_1 : rows = input coordinate c (n + m <= 32), one MFMA per k-step
@@ -141,6 +166,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    GMPC_STAMP(3)
     if (rvalid) {
       float* dst = AB + (size_t)R * nm;
 #pragma unroll
@@ -149,7 +175,11 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
         if (c < nm) dst[c] = acc0[rg] + (c == irow ? 1.0f : 0.0f);
       }
     }
+    GMPC_STAMP(4)
   }
+  if (stamps && lane == 0)
+    for (int i = 0; i < 5; ++i) atomicAdd(&lp.dbg[i], st[i]);
+#undef GMPC_STAMP
 }
 
 template <int NT, int KS>
