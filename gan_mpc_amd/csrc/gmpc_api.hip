@@ -50,6 +50,7 @@ void gmpc_launch_lstm_bwd(int, const CriticDesc&, const float*, const float*, co
                           float*, hipStream_t);
 void gmpc_launch_wgrad(int, int, int, const float*, int, const float*, int, float*, float*, int,
                        float*, int, hipStream_t, long, bool);
+bool gmpc_launch_wgrad_batch(WgProb*, int, float*, long, hipStream_t);
 void gmpc_launch_sum(int, const float*, float*, int, hipStream_t);
 void gmpc_launch_adam(long, float*, const float*, float*, float*, float, int, double, double, double,
                       double, double, float*, hipStream_t);
@@ -658,18 +659,45 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     float* gWx = grad_sum;
     float* gWh = gWx + (long)n * G4;
     float* gb = gWh + (long)F * G4;
-    gmpc_launch_wgrad(rows, n, G4, xseq, n, c->dz, G4, gWx, nullptr, 0, c->wpart, 256, s, c->wpart_floats, true);
-    gmpc_launch_wgrad(rows, F, G4, c->hp, F, c->dz, G4, gWh, gb, rows, c->wpart, 256, s, c->wpart_floats, true);
+    // every problem with N % 256 == 0 goes into one batched launch (+ one reduction launch)
+    WgProb pr[GMPC_WG_MAX];
+    int np = 0;
+    auto add = [&](int r, int M, int N, const float* A, int lda, const float* Bm, int ldb, float* Cw,
+                   float* cs, int cs_rows) {
+      WgProb q{};
+      q.rows = r; q.M = M; q.N = N; q.lda = lda; q.ldb = ldb; q.cs_rows = cs_rows;
+      q.A = A; q.B = Bm; q.C = Cw; q.colsum = cs;
+      pr[np++] = q;
+    };
+    struct Single { int r, M, N; const float* A; int lda; const float* Bm; int ldb; float* Cw; float* cs; int csr; };
+    Single single[GMPC_MAX_LAYERS + 2];
+    int ns = 0;
+    auto route = [&](int r, int M, int N, const float* A, int lda, const float* Bm, int ldb, float* Cw,
+                     float* cs, int cs_rows) {
+      if (N % 256 == 0 && r >= 64 && np < GMPC_WG_MAX) add(r, M, N, A, lda, Bm, ldb, Cw, cs, cs_rows);
+      else single[ns++] = Single{r, M, N, A, lda, Bm, ldb, Cw, cs, cs_rows};
+    };
+    route(rows, n, G4, xseq, n, c->dz, G4, gWx, nullptr, 0);
+    route(rows, F, G4, c->hp, F, c->dz, G4, gWh, gb, rows);
     float* gh = gb + G4;
     int aoff = 0, doff = 0;
     for (int l = 0; l < sh.head_layers; ++l) {
       const int M = sh.head_dims[l], N = sh.head_dims[l + 1];
-      gmpc_launch_wgrad(Bc, M, N, c->hacts + aoff, c->hstride, c->hdels + doff, c->hstride, gh,
-                        gh + (long)M * N, Bc, c->wpart, 256, s, c->wpart_floats, true);
+      route(Bc, M, N, c->hacts + aoff, c->hstride, c->hdels + doff, c->hstride, gh, gh + (long)M * N, Bc);
       gh += (long)M * N + N;
       aoff += M;
       doff += N;
     }
+    if (np > 0 && !gmpc_launch_wgrad_batch(pr, np, c->wpart, c->wpart_floats, s)) {
+      for (int i = 0; i < np; ++i)
+        single[ns++] = Single{pr[i].rows, pr[i].M, pr[i].N, pr[i].A, pr[i].lda, pr[i].B, pr[i].ldb, pr[i].C,
+                              pr[i].colsum, pr[i].cs_rows};
+    }
+    // the rest one by one, after the batch (they reuse the partial-sum buffer: stream order)
+    for (int i = 0; i < ns; ++i)
+      gmpc_launch_wgrad(single[i].r, single[i].M, single[i].N, single[i].A, single[i].lda, single[i].Bm,
+                        single[i].ldb, single[i].Cw, single[i].cs, single[i].csr, c->wpart, 256, s,
+                        c->wpart_floats, true);
   }
   HIP_TRY(hipGetLastError());
   return 0;

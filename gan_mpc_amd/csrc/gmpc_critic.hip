@@ -720,6 +720,180 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_colsum(int cs_rows, int N, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched weight gradients: the five or six row-sum GEMMs of one optimiser step (LSTM input and
+// recurrent kernels, head layers) differ only in their operands, and each is far too small to fill
+// the chip (a few hundred wave-tiles): issued one by one they cost a launch, a tail and a reduction
+// launch each.  Here ONE launch covers the wave-tiles of all problems plus their bias column sums
+// (the trailing workgroups), and ONE launch reduces all the partial sums, in the same fixed chunk
+// order as before (deterministic).  Problems need N % 256 == 0.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GMPC_THREADS) void k_wgrad_batch(WgBatch bt, float* part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x >= bt.gemm_blocks) {
+    // bias column sums: one workgroup per (problem, row chunk)
+    const int cb = blockIdx.x - bt.gemm_blocks;
+    int pi = -1;
+    for (int i = 0; i < bt.np; ++i)
+      if (cb >= bt.p[i].cs_block0 && cb < bt.p[i].cs_block0 + bt.p[i].cchunks) pi = i;
+    if (pi < 0) return;
+    const WgProb& q = bt.p[pi];
+    const int chunk = cb - q.cs_block0;
+    const int r0 = chunk * q.crpc, r1 = min(q.cs_rows, r0 + q.crpc);
+    float* out = part + q.cs_part_off + (size_t)chunk * q.N;
+    for (int j = threadIdx.x; j < q.N; j += blockDim.x) {
+      float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int r = r0;
+      for (; r + 8 <= r1; r += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += q.B[(size_t)(r + u) * q.ldb + j];
+      }
+      for (; r < r1; ++r) a[0] += q.B[(size_t)r * q.ldb + j];
+      out[j] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    return;
+  }
+  constexpr int NTW = 8;
+  const int item = blockIdx.x * (GMPC_THREADS / 64) + wave;
+  int pi = 0;
+  for (int i = 1; i < bt.np; ++i)
+    if (item >= bt.p[i].item0) pi = i;
+  const WgProb& q = bt.p[pi];
+  const int local = item - q.item0;
+  if (local >= q.mstrips * q.ngroups * q.nchunks) return;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int chunk = local / (q.mstrips * q.ngroups);
+  const int rem = local - chunk * q.mstrips * q.ngroups;
+  const int mi = rem / q.ngroups, ng = rem - mi * q.ngroups;
+  const int rows = q.rows, M = q.M, N = q.N;
+  const int r0 = chunk * q.rpc;
+  const int r1 = min(rows, r0 + q.rpc);
+  const int Kp = (r1 - r0 + 1) & ~1;
+  const int acol = mi * 32 + l31;
+  const bool aok = acol < M;
+  const float* ap = q.A + (aok ? acol : M - 1);
+  const int lda = q.lda;
+  auto afn = [&](int k0) -> float {
+    const int r = r0 + k0 + half;
+    const float v = ap[(size_t)min(r, rows - 1) * lda];
+    return (aok && r < r1) ? v : 0.f;
+  };
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
+  const float* bp0 = q.B + (size_t)(r0 + half) * q.ldb + ng * 32 * NTW + l31;
+  gemm_tile<NTW>(bp0, q.ldb, Kp, afn, acc);
+  float* cp = part + q.part_off + (size_t)chunk * M * N;
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int col = ng * 32 * NTW + nt * 32 + l31;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int row = mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+      if (row < M) cp[(size_t)row * N + col] = acc[nt][rg];
+    }
+  }
+}
+
+// all reductions of a batch: blocks [red_block0, ...) of problem i sum its nchunks partial C's,
+// blocks [cs_red_block0, ...) its column-sum partials; same arithmetic as k_reduce_splits
+__global__ __launch_bounds__(256) void k_reduce_batch(WgBatch bt, const float* part) {
+  __shared__ float sh[4][64];
+  int pi = 0, kind = 0;
+  for (int i = 0; i < bt.np; ++i) {
+    const int b_ = (int)blockIdx.x;
+    if (b_ >= bt.p[i].red_block0 && b_ < bt.p[i].cs_red_block0) { pi = i; kind = 0; }
+    if (bt.p[i].colsum != nullptr && b_ >= bt.p[i].cs_red_block0 &&
+        b_ < bt.p[i].cs_red_block0 + (bt.p[i].N + 63) / 64) { pi = i; kind = 1; }
+  }
+  const WgProb& q = bt.p[pi];
+  const int count = kind == 0 ? q.M * q.N : q.N;
+  const int nsplit = kind == 0 ? q.nchunks : q.cchunks;
+  const float* src = part + (kind == 0 ? q.part_off : q.cs_part_off);
+  float* out = kind == 0 ? q.C : q.colsum;
+  const int blk = blockIdx.x - (kind == 0 ? q.red_block0 : q.cs_red_block0);
+  const int el = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int e = blk * 64 + el;
+  const int qn = (nsplit + 3) / 4;
+  const int s0 = seg * qn, s1 = min(nsplit, s0 + qn);
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (e < count) {
+    int sp = s0;
+    for (; sp + 8 <= s1; sp += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += src[(size_t)(sp + u) * count + e];
+    }
+    for (; sp < s1; ++sp) a[0] += src[(size_t)sp * count + e];
+  }
+  sh[seg][el] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  __syncthreads();
+  if (seg == 0 && e < count) out[e] = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
+}
+
+// returns false when a problem does not qualify (the caller then issues them one by one)
+bool gmpc_launch_wgrad_batch(WgProb* probs, int np, float* part, long part_floats, hipStream_t s) {
+  if (np < 1 || np > GMPC_WG_MAX) return false;
+  WgBatch bt;
+  bt.np = np;
+  for (int i = 0; i < np; ++i) {
+    WgProb& q = probs[i];
+    if (q.N % 256 != 0 || q.rows < 64) return false;
+    q.mstrips = (q.M + 31) / 32;
+    q.ngroups = q.N / 256;
+  }
+  // one chunk length (rows per wave-tile) for all problems, so that every wave does the same amount
+  // of work: the shortest one whose partial sums fit the buffer and that needs <= 4096 wave-tiles
+  static const int rpcs[] = {64, 96, 128, 192, 256, 384, 512, 768, 1024, 2048, 4096, 8192, 1 << 30};
+  int rpc = 0;
+  for (int cand : rpcs) {
+    long need = 0, items = 0;
+    for (int i = 0; i < np; ++i) {
+      const WgProb& q = probs[i];
+      const long nch = (q.rows + cand - 1) / cand;
+      need += nch * q.M * q.N + (q.colsum ? 1024L * q.N : 0);
+      items += nch * q.mstrips * q.ngroups;
+    }
+    if (need <= part_floats && items <= 4096) { rpc = cand; break; }
+  }
+  if (rpc == 0) return false;
+  int item = 0, cs_blocks = 0, red_blocks = 0;
+  long off = 0;
+  for (int i = 0; i < np; ++i) {
+    WgProb& q = probs[i];
+    q.rpc = rpc;
+    q.nchunks = (q.rows + rpc - 1) / rpc;
+    q.item0 = item;
+    item += q.mstrips * q.ngroups * q.nchunks;
+    q.part_off = off;
+    off += (long)q.nchunks * q.M * q.N;
+    if (q.colsum != nullptr) {
+      int cchunks = (q.cs_rows + 63) / 64;
+      if (cchunks > 1024) cchunks = 1024;
+      if (cchunks < 1) cchunks = 1;
+      q.crpc = (q.cs_rows + cchunks - 1) / cchunks;
+      q.cchunks = (q.cs_rows + q.crpc - 1) / q.crpc;
+      q.cs_block0 = cs_blocks;
+      cs_blocks += q.cchunks;
+      q.cs_part_off = off;
+      off += (long)q.cchunks * q.N;
+    } else {
+      q.cchunks = 0; q.crpc = 0; q.cs_block0 = cs_blocks; q.cs_part_off = off;
+    }
+    q.red_block0 = red_blocks;
+    red_blocks += (q.M * q.N + 63) / 64;
+    q.cs_red_block0 = red_blocks;
+    if (q.colsum != nullptr) red_blocks += (q.N + 63) / 64;
+    bt.p[i] = q;
+  }
+  if (off > part_floats) return false;
+  bt.gemm_blocks = (item + 3) / 4;
+  hipLaunchKernelGGL(k_wgrad_batch, dim3(bt.gemm_blocks + cs_blocks), dim3(GMPC_THREADS), 0, s, bt, part);
+  hipLaunchKernelGGL(k_reduce_batch, dim3(red_blocks), dim3(256), 0, s, bt, part);
+  return true;
+}
+
 // MFMA path of gmpc_launch_wgrad; returns false when the shape does not qualify.
 bool gmpc_launch_wgrad_mfma(int rows, int M, int N, const float* A, int lda, const float* Bm, int ldb,
                             float* C, float* colsum, int cs_rows, float* part, long part_floats,

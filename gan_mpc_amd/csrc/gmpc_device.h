@@ -215,6 +215,20 @@ struct CriticDesc {
   MlpDesc head;              // dims[0] = F ... dims[L] = 1
 };
 
+// one weight-gradient problem  C[M][N] = sum_r A[r][:M]^T B[r][:N],  colsum[N] = sum_{r<cs_rows} B[r]
+struct WgProb {
+  int rows, M, N, lda, ldb, cs_rows;
+  const float* A; const float* B;
+  float* C; float* colsum;            // colsum may be null
+  // filled by the launcher: tiling and the problem's slices of the partial-sum buffer
+  int mstrips, ngroups, nchunks, rpc, item0;
+  int cchunks, crpc, cs_block0;
+  long part_off, cs_part_off;
+  int red_block0, cs_red_block0;
+};
+#define GMPC_WG_MAX 8
+struct WgBatch { int np; int gemm_blocks; WgProb p[GMPC_WG_MAX]; };
+
 // expert sequence model (gmpc_expert.hip)
 struct ExpertArgs {
   int B, n, m, T, hist, F;       // F == 0: the MLP variant (first = Dense(n -> h) + relu)
