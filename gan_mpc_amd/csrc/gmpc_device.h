@@ -171,6 +171,7 @@ struct TrajArgs {
   int* iters;           // [B] in/out
   float alpha_0, alpha_min;
   int aw, pw;           // LDS sizing (float4 counts): activation buffers, partial-sum buffer
+  int sw0, swl;         // floats of LDS holding W_0 (first layer) / W_L (output layer); 0: not staged
   // line search: the work list of this round; slot = one (trajectory, halving count) candidate,
   // candidate i writes Xc / Uc / maskc / objc at index i
   const int* item_b; const int* item_k; const int* nitems;

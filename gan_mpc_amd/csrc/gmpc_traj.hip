@@ -11,6 +11,8 @@
 // policy/optimizers.py:19,26-29,55.
 #include "gmpc_device.h"
 
+#define GMPC_TRAJ_THREADS_ 512   // workgroup size of k_traj (see GMPC_TRAJ_THREADS)
+
 
 // One hidden layer for the 4 trajectories of the block: z = act_in . W + b; mask bits; relu.
 // mbase points at mask word 0 of (trajectory 0, this step, this layer); trajectory c sits
@@ -57,6 +59,37 @@ __device__ __forceinline__ void hidden_layer(const float* W, const float* bias, 
                             fmaxf(acc[0].w, 0.f));
 }
 
+// Output layer of the trajectory kernels for n <= 32: out[j] = sum_k W[k][j] act[k].  512 threads =
+// 32 output slots x 16 K-slices; the two slices of a wave meet by a lane-half exchange, the 8 wave
+// partials through LDS (`part`, 8 x 32 float4), summed in wave order by the caller-visible result
+// part[j].  (dense_small's generic form put 30 thread groups' partials through LDS and summed them
+// one after the other: 6.2k of the 27.6k cycles of a rollout step.)
+__device__ __forceinline__ void out_layer32(const float* W, int K, int n, const float4* act, float4* part) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = tid & 31, kq = tid >> 5;                 // 16 K-slices
+  const int Kq = (K + 15) >> 4;
+  const int k0 = kq * Kq, k1 = min(K, k0 + Kq);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (j < n) {
+    const float* wp = W + j;
+    for (int k = k0; k < k1; ++k) fma4(acc, wp[(size_t)k * n], act[k]);
+  }
+  acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32);
+  acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+  if (lane < 32) part[32 + wave * 32 + j] = acc;         // slots 32.. : wave partials
+  __syncthreads();
+  if (tid < n) {
+    float4 s = part[32 + tid];
+#pragma unroll
+    for (int w = 1; w < GMPC_TRAJ_THREADS_ / 64; ++w) {
+      const float4 p = part[32 + w * 32 + tid];
+      s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    part[tid] = s;
+  }
+  __syncthreads();
+}
+
 #ifndef GMPC_TRAJ_MINW
 #define GMPC_TRAJ_MINW 4
 #endif
@@ -71,6 +104,9 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
   float4* const part = actB + a.aw;
   float4* const ksp = part + a.pw;
   float4* const xcur = ksp + GMPC_THREADS;
+  // the two small weight matrices live in LDS for the whole horizon when they fit (launcher decides)
+  float* const w0_s = reinterpret_cast<float*>(xcur + a.n);
+  float* const wl_s = w0_s + a.sw0;
   __shared__ float s_alpha[GMPC_TB];
   __shared__ int s_bi[GMPC_TB], s_in[GMPC_TB];
 
@@ -109,6 +145,10 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
   auto CI = [&](int c) -> size_t { return (size_t)(b0 + c); };
   const int Lh = a.dyn.L - 1;
   const size_t mstride = (size_t)T * Lh * GMPC_MW;   // mask words per trajectory
+  for (int e = tid; e < a.sw0; e += blockDim.x) w0_s[e] = a.dyn.W[0][e];
+  for (int e = tid; e < a.swl; e += blockDim.x) wl_s[e] = a.dyn.W[Lh][e];
+  const float* const W0 = a.sw0 ? w0_s : a.dyn.W[0];
+  const float* const WL = a.swl ? wl_s : a.dyn.W[Lh];
   const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]), w2 = sigmoidf_(a.mpc_w[2]);
 
   {
@@ -130,7 +170,16 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
       }
     }
     float objacc = 0.f;  // lane 0 of wave c accumulates trajectory c
+    // goal of the NEXT step, one element per lane of wave c (n <= 64): its load overlaps a whole step
+    float gnext = 0.f;
+    if (n <= 64 && wave < GMPC_TB && lane < n) gnext = a.goal[(size_t)BI(wave) * (T + 1) * n + lane];
     __syncthreads();
+#ifdef GMPC_TRAJ_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = __builtin_readcyclecounter();
+#define TS_(i) { const unsigned long long t_ = __builtin_readcyclecounter(); st_[i] += t_ - tp_; tp_ = t_; }
+#else
+#define TS_(i)
+#endif
 
     for (int t = 0; t < T; ++t) {
       // ---- controls and layer-0 input
@@ -162,15 +211,25 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
         aAf[(n + j) * 4 + c] = a.U[((size_t)BI(c) * T + t) * m + j];
       }
       __syncthreads();
+      TS_(0)
       // ---- stage cost of (x_t, u_t): wave c (< 4) handles trajectory c
       if (wave < GMPC_TB) {
         const int c = wave;
         float dd = 0.f, uu = 0.f;
         const int bc = BI(c);
         const float* g = a.goal + ((size_t)bc * (T + 1) + t) * n;
-        for (int i = lane; i < n; i += 64) {
-          const float d = aAf[i * 4 + c] - g[i];
-          dd = fmaf(d, d, dd);
+        if (n <= 64) {
+          const float gi = gnext;
+          if (lane < n) {
+            gnext = g[n + lane];           // row t + 1 (exists: the goal has T + 1 rows)
+            const float d = aAf[lane * 4 + c] - gi;
+            dd = d * d;
+          }
+        } else {
+          for (int i = lane; i < n; i += 64) {
+            const float d = aAf[i * 4 + c] - g[i];
+            dd = fmaf(d, d, dd);
+          }
         }
         for (int j = lane; j < m; j += 64) {
           const float u = aAf[(n + j) * 4 + c];
@@ -183,25 +242,29 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
         objacc += cst;
         if (!LS && lane == 0 && INB(c) && a.costs) a.costs[(size_t)bc * (T + 1) + t] = cst;
       }
+      TS_(1)
       // ---- hidden layers
       float4* in = actA;
       float4* out = actB;
       for (int l = 0; l < Lh; ++l) {
         // the tail block's clamped trajectories never write (wbits), so b0-relative addressing is safe
         uint32_t* mbase = (LS ? a.maskc : a.masks) + (size_t)b0 * mstride + ((size_t)t * Lh + l) * GMPC_MW;
-        hidden_layer(a.dyn.W[l], a.dyn.b[l], a.dyn.dims[l], a.dyn.dims[l + 1], in, out, mbase, mstride,
-                     wbits, ksp);
+        hidden_layer(l == 0 ? W0 : a.dyn.W[l], a.dyn.b[l], a.dyn.dims[l], a.dyn.dims[l + 1], in, out, mbase,
+                     mstride, wbits, ksp);
         __syncthreads();
+        TS_(2 + l)
         float4* tmp = in; in = out; out = tmp;
       }
       // ---- output layer + residual
-      if (n <= (int)blockDim.x) {
-        dense_small<1>(a.dyn.W[Lh], a.dyn.dims[Lh], n, in, part);
+      if (n <= 32) {
+        out_layer32(WL, a.dyn.dims[Lh], n, in, part);
+      } else if (n <= (int)blockDim.x) {
+        dense_small<1>(WL, a.dyn.dims[Lh], n, in, part);
       } else {
         // wide state (n > 512): one output per thread, chunk after chunk
         for (int jb = 0; jb < n; jb += blockDim.x) {
           float4 acc[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
-          dense_rows<1>(a.dyn.W[Lh], a.dyn.dims[Lh], n, jb + tid, in, acc);
+          dense_rows<1>(WL, a.dyn.dims[Lh], n, jb + tid, in, acc);
           if (jb + tid < n) part[jb + tid] = acc[0];
         }
         __syncthreads();
@@ -220,7 +283,13 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
             Xo[((LS ? CI(c) : (size_t)BI(c)) * (T + 1) + t + 1) * n + i] = f4get(v, c);
       }
       __syncthreads();
+      TS_(6)
     }
+#ifdef GMPC_TRAJ_STAMPS
+    if (blockIdx.x == 0 && (tid == 0 || tid == 256))
+      printf("tid %d: staging %llu cost %llu L0 %llu L1 %llu L2 %llu out %llu (cycles per step)\n", tid,
+             st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T, st_[6] / T);
+#endif
     // ---- terminal cost w2 * |cost_mlp(x_T)|^2
     {
       float4* in = xcur;
@@ -424,7 +493,14 @@ static int traj_aw(int n, int m, const MlpDesc& d1, const MlpDesc* d2) {
 static size_t traj_lds(TrajArgs& a) {
   a.aw = traj_aw(a.n, a.m, a.dyn, &a.cost);
   a.pw = a.n > GMPC_TRAJ_THREADS ? a.n : GMPC_TRAJ_THREADS;
-  return ((size_t)2 * a.aw + a.pw + GMPC_THREADS + a.n) * sizeof(float4);
+  size_t bytes = ((size_t)2 * a.aw + a.pw + GMPC_THREADS + a.n) * sizeof(float4);
+  // W_0 and W_L in LDS while the workgroup stays under 64 KB (two workgroups per CU in the line search)
+  const int Lh = a.dyn.L - 1;
+  const size_t w0 = (size_t)a.dyn.dims[0] * a.dyn.dims[1], wl = (size_t)a.dyn.dims[Lh] * a.n;
+  a.sw0 = a.swl = 0;
+  if (bytes + w0 * sizeof(float) <= 64 * 1024) { a.sw0 = (int)w0; bytes += w0 * sizeof(float); }
+  if (bytes + wl * sizeof(float) <= 64 * 1024) { a.swl = (int)wl; bytes += wl * sizeof(float); }
+  return bytes;
 }
 // dynamic LDS above the default 64 KB needs the attribute; the kernels also hold a few hundred bytes
 // of static LDS, so the full 160 KB cannot be requested
