@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/gan_mpc_amd.h"
 
@@ -20,10 +21,24 @@ struct MlpDesc {
   const float* b[GMPC_MAX_LAYERS];
 };
 
+// Sum over the 64 lanes, result in every lane.  Data-parallel-primitive moves instead of
+// __shfl_xor: the shuffle compiles to ds_bpermute_b32, a round trip through the LDS crossbar (~150
+// cycles each, six per sum), DPP row operations are plain VALU modifiers.  Steps: within quads, within
+// rows of 16 (mirrors), then row_bcast15 / row_bcast31 carry the row sums into lane 63, which is
+// broadcast with v_readlane.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  auto dpp = [](float x, auto ctrl, auto row_mask) -> float {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value,
+                                                      decltype(row_mask)::value, 0xF, false));
+  };
+  using std::integral_constant;
+  v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xF>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xF>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xF>{});   // row_half_mirror
+  v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xF>{});   // row_mirror
+  v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xA>{});   // row_bcast15 -> rows 1, 3
+  v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xC>{});   // row_bcast31 -> rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ void fma4(float4& acc, float w, const float4& a) {
