@@ -18,6 +18,8 @@
 //
 // Compile-time shape: NT row tiles (hidden width <= 32 NT) and KS k-steps (hidden width = 2 KS or
 // 2 KS - 1), all hidden layers of the same width, n + m <= 32.  Everything else runs the LDS variant.
+#include <cstdlib>
+
 #include "gmpc_device.h"
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -34,11 +36,19 @@ __device__ __forceinline__ void swap_halves(float& a, float& b) {
   b = __uint_as_float(r.y);
 }
 
-template <int NT, int KS>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// TAIL = 8: the hidden width is 32 NT + 8 (200 = 6 x 32 + 8).  A seventh 32-row tile would be three
+// quarters padding; instead the last 8 rows go through v_mfma_f32_4x4x1_16B_f32, whose 16 blocks of
+// 4 x 4 are exactly 2 row groups x 8 column groups of this tile: one issue per k (8 cycles) instead
+// of a quarter-used 64-cycle issue per two k.  Its B operand wants the k row in BOTH lane halves (one
+// v_permlane32_swap of S[ks] with itself gives the rows 2 ks and 2 ks + 1 that way), its A operand
+// -- 8 weights per k -- comes from a small LDS table.
+template <int NT, int KS, int TAIL = 0>
 __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
     int NSamp, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
     float* AB, int ntiles, int samp_mul, int samp_add) {
-  static_assert(NT <= 8 && 2 * KS <= 32 * NT, "shape");
+  static_assert(NT <= 8 && 2 * KS <= 32 * NT + TAIL && (TAIL == 0 || TAIL == 8), "shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wl_s = reinterpret_cast<float*>(smem);          // W_L  [(H + pad)][n]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -47,6 +57,16 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
   const int Rtot = NSamp * n;
   const int wl_floats = (dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;
   for (int e = threadIdx.x; e < wl_floats; e += blockDim.x) wl_s[e] = lp.WLP[e];
+  // tail rows 32 NT .. 32 NT + 7 of every hidden W_l^T: wt_s[l - 1][k][8]
+  float* wt_s = wl_s + wl_floats;
+  if (TAIL > 0) {
+    for (int l = 1; l < Lh; ++l)
+      for (int e = threadIdx.x; e < 2 * KS * 8; e += blockDim.x) {
+        const int k = e >> 3, r = e & 7;
+        // lane-interleaved source: row k of W_l^T, slot of input row 32 NT + r
+        wt_s[(l - 1) * 2 * KS * 8 + e] = lp.WTP[l][(size_t)k * 256 + r * 8 + NT];
+      }
+  }
   __syncthreads();   // the only workgroup barrier
   // diagnostic stamps (GMPC_LIN_STAMPS=1): 0 seed, 1 hidden GEMMs, 2 epilogues, 3 input GEMM, 4 stores
   unsigned long long st[5] = {0, 0, 0, 0, 0}, tprev = 0;
@@ -69,11 +89,11 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
     const uint32_t* mrow = masks + sid * Lh * GMPC_MW;
 
     // ---- seed: S[ks] = W_L[2 ks + half][irow] * relu bit of hidden layer Lh-1
-    float S[16 * NT];
+    float S[16 * NT + TAIL / 2];
     {
-      uint32_t mw[NT];
+      uint32_t mw[NT + 1];
 #pragma unroll
-      for (int w = 0; w < NT; ++w) mw[w] = mrow[(Lh - 1) * GMPC_MW + w] >> half;
+      for (int w = 0; w < NT + (TAIL > 0 ? 1 : 0); ++w) mw[w] = mrow[(Lh - 1) * GMPC_MW + w] >> half;
       const float* wl = wl_s + half * n + irow;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -97,9 +117,16 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
 #pragma unroll
       for (int j = 0; j < RD - 1; ++j) { w[j][0] = bp[j * 128]; w[j][1] = bp[j * 128 + 1]; }
       // relu words of the layer this GEMM produces (loaded early, used in the epilogue)
-      uint32_t mw[NT];
+      uint32_t mw[NT + 1];
 #pragma unroll
-      for (int t_ = 0; t_ < NT; ++t_) mw[t_] = mrow[(l - 1) * GMPC_MW + t_] >> (4 * half);
+      for (int t_ = 0; t_ < NT + (TAIL > 0 ? 1 : 0); ++t_) mw[t_] = mrow[(l - 1) * GMPC_MW + t_] >> (4 * half);
+      // two tail accumulators (even / odd k): back-to-back 4x4x1 issues into one accumulator would
+      // wait for each other; the A operands are read from LDS one k-step ahead
+      f32x4 acct = {0.f, 0.f, 0.f, 0.f}, acct2 = {0.f, 0.f, 0.f, 0.f};
+      const float* wtl = wt_s + (l - 1) * 2 * KS * 8 + 4 * half + (lane & 3);
+      float wte = TAIL > 0 ? wtl[0] : 0.f, wto = TAIL > 0 ? wtl[8] : 0.f;
+      float bte = S[0], bto = S[0];          // B operands of the tail, prepared one k-step ahead
+      if (TAIL > 0) swap_halves(bte, bto);   // bte: row 2 ks in both lane halves, bto: row 2 ks + 1
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + RD - 1 < KS) {
@@ -116,6 +143,19 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
         if (NT > 5) acc[5 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.y, b, acc[5 % NT], 0, 0, 0);
         if (NT > 6) acc[6 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.z, b, acc[6 % NT], 0, 0, 0);
         if (NT > 7) acc[7 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.w, b, acc[7 % NT], 0, 0, 0);
+        if (TAIL > 0) {
+          const float be = bte, bo = bto;
+          const float ae = wte, ao = wto;
+          if (ks + 1 < KS) {
+            wte = wtl[(2 * ks + 2) * 8];
+            wto = wtl[(2 * ks + 3) * 8];
+            bte = S[ks + 1 < KS ? ks + 1 : ks];
+            bto = bte;
+            swap_halves(bte, bto);
+          }
+          acct = __builtin_amdgcn_mfma_f32_4x4x1f32(ae, be, acct, 0, 0, 0);
+          acct2 = __builtin_amdgcn_mfma_f32_4x4x1f32(ao, bo, acct2, 0, 0, 0);
+        }
         // spread the two weight loads and their address arithmetic BETWEEN the MFMAs of the k-step:
         // issued as a block at the k-step boundary they do not overlap the matrix pipe (one wave per
         // SIMD), see gemm_tile_x4
@@ -123,9 +163,10 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
         // pattern -- the NT = 2 instantiation failed its parity test, so it keeps plain program order)
         if (NT >= 4) {
 #pragma unroll
-          for (int i_ = 0; i_ < NT; ++i_) {
+          for (int i_ = 0; i_ < NT + (TAIL > 0 ? 2 : 0); ++i_) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // <= 1 VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // <= 1 LDS read
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // <= 2 VALU
             __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);   // <= 2 SALU
           }
@@ -145,6 +186,15 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
           S[(nt * 32 + rho) / 2] = a0;
           S[(nt * 32 + rho + 4) / 2] = a1;
         }
+      }
+      if (TAIL > 0) {
+        // tail accumulator: lane half h holds rows 32 NT + 4 h + {0..3} of its column
+        acct += acct2;
+        float c0 = ((mw[NT] >> 0) & 1u) ? acct[0] : 0.f, c1 = ((mw[NT] >> 1) & 1u) ? acct[1] : 0.f;
+        float c2 = ((mw[NT] >> 2) & 1u) ? acct[2] : 0.f, c3 = ((mw[NT] >> 3) & 1u) ? acct[3] : 0.f;
+        swap_halves(c0, c1);      // c0: rows (+0, +1); c1: rows (+4, +5)
+        swap_halves(c2, c3);      // c2: rows (+2, +3); c3: rows (+6, +7)
+        S[16 * NT + 0] = c0; S[16 * NT + 1] = c2; S[16 * NT + 2] = c1; S[16 * NT + 3] = c3;
       }
       GMPC_STAMP(2)
     }
@@ -182,7 +232,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
 #undef GMPC_STAMP
 }
 
-template <int NT, int KS>
+template <int NT, int KS, int TAIL = 0>
 static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
                        const uint32_t* masks, const int* active, float* AB, int samp_mul, int samp_add,
                        hipStream_t s) {
@@ -190,11 +240,12 @@ static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const
   if (Rtot >= (1L << 31) - 64) return -1;
   const int ntiles = (int)((Rtot + 31) / 32);
   const int Lh = dyn.L - 1;
-  const size_t lds = (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n * sizeof(float);
+  size_t lds = (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n * sizeof(float);
+  if (TAIL > 0) lds += (size_t)(Lh - 1) * 2 * KS * 8 * sizeof(float);
   if (lds > 64 * 1024) return -1;
   int grid = (ntiles + 3) / 4;
   if (grid > 256) grid = 256;   // one persistent workgroup per CU (one wave per SIMD: 512 registers)
-  hipLaunchKernelGGL((k_linearize_regs<NT, KS>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
+  hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
                      dyn, lp, masks, active, AB, ntiles, samp_mul, samp_add);
   return 0;
 }
@@ -208,8 +259,12 @@ int gmpc_launch_linearize_regs(int NSamp, int T, int n, int m, const MlpDesc& dy
   const int H = dyn.dims[1];
   for (int l = 1; l <= Lh; ++l)
     if (dyn.dims[l] != H) return -1;
-  if (H == 200 && lp.NT == 7)
+  if (H == 200 && lp.NT == 7) {
+    static const bool no_tail = getenv("GMPC_LIN_NOTAIL") != nullptr;
+    if (!no_tail)
+      return launch_regs<6, 100, 8>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
     return launch_regs<7, 100>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
+  }
   if (H == 128 && lp.NT == 4)
     return launch_regs<4, 64>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
   if (H == 64 && lp.NT == 2)
