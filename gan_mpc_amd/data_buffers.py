@@ -1,6 +1,9 @@
-"""History buffer for acting in an environment and the replay buffer of (x, u, x') windows
-(reference data_buffers.py:8-77, same names).  Windows are cut with one strided view per trajectory
-instead of a Python loop per element."""
+"""The two buffers around the environment loop (reference data_buffers.py:8-77, same names):
+`Buffer` keeps the recent normalised history the policy is conditioned on, `ReplayBuffer` the
+horizon-long (states, actions, next states) windows the dynamics model is refitted on.
+
+Windows are cut with one strided view per trajectory instead of a Python loop per window, and the
+replay buffer keeps whole window blocks (one per added trajectory) rather than single windows."""
 
 import collections
 
@@ -18,12 +21,12 @@ def sliding_windows(traj, length, count, start=0):
 
 
 class Buffer:
-    """Last `maxlen`+1 normalised states and `maxlen` actions (reference data_buffers.py:8-30)."""
+    """The last `maxlen` + 1 normalised states and `maxlen` actions (reference :8-30)."""
 
     def __init__(self, maxlen, normalizer):
+        self.normalizer = normalizer
         self.x_queue = collections.deque(maxlen=maxlen + 1)
         self.u_queue = collections.deque(maxlen=maxlen)
-        self.normalizer = normalizer
 
     def append_state(self, x, *args):
         self.x_queue.append(self.normalizer.normalize_state(x))
@@ -38,42 +41,71 @@ class Buffer:
         return np.array(self.u_queue)
 
     def clear(self):
-        self.x_queue.clear()
-        self.u_queue.clear()
+        for queue in (self.x_queue, self.u_queue):
+            queue.clear()
 
 
 class ReplayBuffer:
-    """FIFO of horizon-long (states, actions, next states) windows (reference :33-77)."""
+    """First-in-first-out store of at most `q_maxlen` windows (reference :33-77)."""
+
+    _FIELDS = ("state", "action", "next_state")
 
     def __init__(self, horizon, q_maxlen, normalizer):
         self.horizon = horizon
-        self.state_queue = collections.deque(maxlen=q_maxlen)
-        self.action_queue = collections.deque(maxlen=q_maxlen)
-        self.next_state_queue = collections.deque(maxlen=q_maxlen)
+        self.q_maxlen = q_maxlen
         self.normalizer = normalizer
+        self.clear()
 
     def clear(self):
-        self.state_queue.clear()
-        self.action_queue.clear()
-        self.next_state_queue.clear()
+        self._blocks = {name: [] for name in self._FIELDS}     # arrays of windows, oldest first
+        self._count = 0
+
+    def __len__(self):
+        return self._count
 
     def from_traj_to_seq(self, state_traj, action_traj):
-        H = self.horizon
-        count = len(state_traj) - H
+        """(states, actions, next states) windows of one trajectory; a trajectory no longer than the
+        horizon yields three empty arrays of shape (0,), like the reference's np.array([])."""
         state_traj, action_traj = np.asarray(state_traj), np.asarray(action_traj)
-        if count <= 0:       # np.array([]) in the reference: keep its (0,) shape
+        count = len(state_traj) - self.horizon
+        if count <= 0:
             return np.array([]), np.array([]), np.array([])
+        H = self.horizon
         return (sliding_windows(state_traj, H, count), sliding_windows(action_traj, H, count),
                 sliding_windows(state_traj, H, count, start=1))
 
     def add(self, state_traj, action_traj):
-        state_traj = self.normalizer.normalize_state(state_traj)
-        action_traj = self.normalizer.normalize_action(action_traj)
-        xs, us, ys = self.from_traj_to_seq(state_traj, action_traj)
-        self.state_queue.extend(xs)
-        self.action_queue.extend(us)
-        self.next_state_queue.extend(ys)
+        windows = self.from_traj_to_seq(self.normalizer.normalize_state(state_traj),
+                                        self.normalizer.normalize_action(action_traj))
+        if len(windows[0]) == 0:
+            return
+        for name, block in zip(self._FIELDS, windows):
+            self._blocks[name].append(block)
+        self._count += len(windows[0])
+        self._trim()
+
+    def _trim(self):
+        """Drop the oldest windows beyond q_maxlen (whole blocks first, then the head of a block)."""
+        excess = self._count - self.q_maxlen
+        while excess > 0:
+            head = len(self._blocks["state"][0])
+            if head <= excess:
+                for name in self._FIELDS:
+                    self._blocks[name].pop(0)
+                excess -= head
+                self._count -= head
+            else:
+                for name in self._FIELDS:
+                    self._blocks[name][0] = self._blocks[name][0][excess:]
+                self._count -= excess
+                excess = 0
 
     def get_dataset(self):
-        return (np.array(self.state_queue), np.array(self.action_queue),
-                np.array(self.next_state_queue))
+        if self._count == 0:
+            return np.array([]), np.array([]), np.array([])
+        return tuple(np.concatenate(self._blocks[name], axis=0) for name in self._FIELDS)
+
+    # the reference exposes its three deques; keep read access to the same names
+    state_queue = property(lambda self: list(self.get_dataset()[0]))
+    action_queue = property(lambda self: list(self.get_dataset()[1]))
+    next_state_queue = property(lambda self: list(self.get_dataset()[2]))

@@ -1,70 +1,67 @@
-"""Critic training (reference gan/critic_trainer.py:12-104): dataset = true sequences (+1) and the
-iLQR-predicted ones (-1); minibatches of critic_loss_and_grad + clip/Adam; test loss."""
+"""Training of the discriminator (reference gan/critic_trainer.py:12-104).  The dataset is rebuilt at
+every call: the true state sequences labelled +1 and, labelled -1, what the current MPC policy
+predicts from the same histories (one batched iLQR solve per split); then passes of
+critic_loss_and_grad + clip/Adam over sampled minibatches and the test loss."""
 
 import numpy as np
 import torch
 
-from gan_mpc_amd import parallel, utils
-from gan_mpc_amd.norm.cost_trainer import _expert_select, _rng
+from gan_mpc_amd import parallel, trainer_common as tc, utils
+
+
+def _labelled_pairs(policy, params, split, row_offset):
+    """(true ⊕ predicted sequences, ±1 labels) of one split, on the device."""
+    X, true_Y = split
+    count = true_Y.shape[0]
+    tc.select_expert_rows(policy, np.arange(count) + row_offset)
+    xc, *_ = policy.get_optimal_values(params, X)                 # (count, T+1, n + carry)
+    predicted = xc[..., :X.shape[-1]]
+    true_t = torch.as_tensor(np.asarray(true_Y, np.float32), device=predicted.device)
+    labels = torch.cat([torch.ones(count), -torch.ones(count)]).to(predicted.device)
+    return torch.cat([true_t, predicted], dim=0).contiguous(), labels
 
 
 def get_dataset(policy, params, true_dataset, key):
-    rng = _rng(key)
-
-    def func(X, true_Y, offset):
-        datasize = true_Y.shape[0]
-        _expert_select(policy, np.arange(datasize) + offset)
-        xc, *_ = policy.get_optimal_values(params, X)          # (N, T+1, n) device
-        xsize = X.shape[-1]
-        pred_Y = xc[..., :xsize]
-        true_t = torch.as_tensor(np.asarray(true_Y, np.float32), device=pred_Y.device)
-        label = torch.cat([torch.ones(datasize), -torch.ones(datasize)]).to(pred_Y.device)
-        return torch.cat([true_t, pred_Y], dim=0).contiguous(), label
-
-    true_train_data, true_test_data = true_dataset
-    train_X, train_label = func(*true_train_data, 0)
-    test_X, test_label = func(*true_test_data, true_train_data[0].shape[0])
-    perm = torch.as_tensor(rng.permutation(train_X.shape[0]), device=train_X.device)
-    return (train_X[perm], train_label[perm]), (test_X, test_label)
+    """reference :12-38 -> ((train_X, train_label) shuffled, (test_X, test_label))"""
+    train_split, test_split = true_dataset
+    train_X, train_label = _labelled_pairs(policy, params, train_split, 0)
+    test_pair = _labelled_pairs(policy, params, test_split, train_split[0].shape[0])
+    order = torch.as_tensor(tc.as_rng(key).permutation(train_X.shape[0]), device=train_X.device)
+    return (train_X[order], train_label[order]), test_pair
 
 
 def calculate_loss(policy, params, dataset):
-    X, Y = dataset
+    X, labels = dataset
     lo, hi = parallel.shard_range(X.shape[0])
-    dparams = policy.to_device_params(params)
-    ls, _ = policy._critic_sums(X[lo:hi].contiguous(), Y[lo:hi].contiguous(), dparams)
-    return parallel.allreduce_mean_from_sums(ls.reshape(1).clone(), hi - lo)[0]
+    loss_sum, _ = policy._critic_sums(X[lo:hi].contiguous(), labels[lo:hi].contiguous(),
+                                      policy.to_device_params(params))
+    return parallel.allreduce_mean_from_sums(loss_sum.reshape(1).clone(), hi - lo)[0]
 
 
 def train_critic_parameters(train_args, opt_state, params, perm, dataset):
     policy, opt = train_args
-    X, Y = dataset
-    losses = []
-    for p in perm:
-        lo, hi = parallel.shard_range(len(p))
-        idx = torch.as_tensor(p[lo:hi], device=X.device)
-        loss, grads = policy.critic_loss_and_grad(X[idx].contiguous(), Y[idx].contiguous(), params)
-        params, opt_state = opt.update(policy._engine, params, grads, opt_state)
-        losses.append(loss)
-    return params, opt_state, sum(float(l) for l in losses) / len(losses)
+    X, labels = dataset
+
+    def step(idx):
+        rows = torch.as_tensor(idx, device=X.device)
+        return policy.critic_loss_and_grad(X[rows].contiguous(), labels[rows].contiguous(), params)
+
+    return tc.sgd_pass(policy, opt, opt_state, params, perm, step)
 
 
 @utils.timeit
 def train(train_args, opt_state, params, true_dataset, num_updates, batch_size, key, id):
     del id
     policy, opt = train_args
-    rng = _rng(key)
+    rng = tc.as_rng(key)
     params = policy.to_device_params(params)
     train_data, test_data = get_dataset(policy, params, true_dataset, rng)
     datasize = train_data[0].shape[0]
-    steps_per_update = datasize // batch_size
     train_losses, test_losses = [], []
-    for _ in range(1, num_updates + 1):
-        perm = rng.choice(datasize, size=(steps_per_update, batch_size))
-        params, opt_state, train_loss = train_critic_parameters(
-            train_args=(policy, opt), opt_state=opt_state, params=params, perm=perm,
-            dataset=train_data)
-        test_loss = calculate_loss(policy=policy, params=params, dataset=test_data)
-        train_losses.append(float(train_loss))
-        test_losses.append(float(test_loss))
+    for _ in range(num_updates):
+        schedule = tc.minibatch_schedule(rng, datasize, batch_size)
+        params, opt_state, loss = train_critic_parameters((policy, opt), opt_state, params, schedule,
+                                                          train_data)
+        train_losses.append(float(loss))
+        test_losses.append(float(calculate_loss(policy, params, test_data)))
     return params, opt_state, train_losses, test_losses

@@ -10,11 +10,9 @@ the teacher-forcing schedule and the environment loop are host code with the ref
 import numpy as np
 import torch
 
-from gan_mpc_amd import parallel, utils
+from gan_mpc_amd import parallel, trainer_common as tc, utils
 
-
-def _rng(key):
-    return key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+_rng = tc.as_rng
 
 
 def _loss_and_grad(policy, dparams, X, U, Y, discount_factor, teacher_forcing):
@@ -42,15 +40,11 @@ def train_per_update(train_args, opt_state, params, perm, dataset, discount_fact
     """reference :50-90: scan over the minibatches of `perm`: mean loss -> grads -> clip+Adam."""
     policy, opt = train_args
     X, U, Y = dataset
-    losses = []
-    for p in perm:
-        lo, hi = parallel.shard_range(len(p))
-        ps = p[lo:hi]
-        loss, grads = _loss_and_grad(policy, params, X[ps], U[ps], Y[ps], discount_factor,
-                                     teacher_forcing)
-        params, opt_state = opt.update(policy._engine, params, grads, opt_state)
-        losses.append(loss)
-    return params, opt_state, sum(float(l) for l in losses) / len(losses)
+
+    def step(idx):
+        return _loss_and_grad(policy, params, X[idx], U[idx], Y[idx], discount_factor, teacher_forcing)
+
+    return tc.sgd_pass(policy, opt, opt_state, params, perm, step)
 
 
 def train_params(train_args, opt_state, params, dataset, num_updates, batch_size, discount_factor,
@@ -66,7 +60,7 @@ def train_params(train_args, opt_state, params, dataset, num_updates, batch_size
     if steps_per_update == 0:
         return params, opt_state, train_losses
     for up in range(1, num_updates + 1):
-        perm = rng.choice(datasize, size=(steps_per_update, batch_size))
+        perm = tc.minibatch_schedule(rng, datasize, batch_size)
         teacher_forcing = (id + up) <= (num_updates * teacher_forcing_factor)
         params, opt_state, train_loss = train_per_update(
             train_args=train_args, opt_state=opt_state, params=params, perm=perm, dataset=dataset,
