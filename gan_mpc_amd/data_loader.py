@@ -1,8 +1,15 @@
-"""Expert-trajectory loader and the training-set windowing (reference data_loader.py:12-129).
+"""Expert trajectories -> training sets (the behaviour of reference data_loader.py:12-129 behind the
+same class and method names).
 
-Same class, method names and selection rules; differences: `key` is a NumPy seed or Generator (the
-JAX threefry permutation is not reproduced), windows are cut with strided views, and the trajectory
-file may be given explicitly (`init(path=...)`) because no dataset ships with either repository."""
+trajectories.json holds {"states": [N][L][n], "actions": [N][L][m], "rewards": [N][L]}.  The loader
+keeps the best trajectories, fits the normaliser on them and cuts three kinds of windows:
+  cost set      X = the history+1 states up to step i (zeros before the start), Y = the horizon+1
+                states from step i on
+  expert set    (states, actions, next states) windows of `seqlen` steps
+  dynamics set  the training split of the expert set with seqlen = horizon
+Differences from the reference: `key` is a NumPy seed or Generator (the JAX threefry permutation is
+not reproduced), windows are strided views instead of Python loops, and the file may be named
+explicitly (`init(path=...)`) because no dataset ships with either repository."""
 
 import json
 import os
@@ -12,11 +19,17 @@ import numpy as np
 from gan_mpc_amd.data_buffers import sliding_windows
 
 _MAIN_DIR_PATH = os.path.dirname(__file__)
-_REWARD_THRESHOLD = 500      # reference data_loader.py:24-28 ("ensure expert trajectories are proper")
+_MIN_RETURN = 500      # reference data_loader.py:24-28: trajectories at or below this return are dropped
+_FIELDS = ("states", "actions", "rewards")
 
 
-def _rng(key):
+def _generator(key):
     return key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+
+
+def _stack(per_trajectory):
+    """[(a0, b0, ...), (a1, b1, ...)] -> (concat a, concat b, ...)"""
+    return tuple(np.concatenate(parts, axis=0) for parts in zip(*per_trajectory))
 
 
 class DataLoader:
@@ -25,73 +38,73 @@ class DataLoader:
         self.normalizer = normalizer
         self.expert_trajectories = None
 
+    # ---- loading ---------------------------------------------------------------------------------
     def get_expert_trajectories(self, path, num_trajectories, trajectory_len):
-        """Best `num_trajectories` by summed reward among those above the threshold, first
-        `trajectory_len` steps of each (reference :18-33)."""
+        """The `num_trajectories` highest-return trajectories above the threshold, cut to
+        `trajectory_len` steps (reference :18-33)."""
         with open(path, "r") as fp:
-            data = json.load(fp)
-        total = np.sum(data["rewards"], axis=1)
-        order = np.argsort(-total)
-        idx = [i for i in order if total[i] > _REWARD_THRESHOLD][:num_trajectories]
-        return {k: np.array(data[k])[idx, :trajectory_len]
-                for k in ("states", "actions", "rewards") if k in data}
+            raw = json.load(fp)
+        returns = np.sum(raw["rewards"], axis=1)
+        ranked = [i for i in np.argsort(-returns) if returns[i] > _MIN_RETURN]
+        keep = ranked[:num_trajectories]
+        return {name: np.array(raw[name])[keep, :trajectory_len] for name in _FIELDS if name in raw}
 
     def init(self, path=None):
-        config = self.config
+        train_cfg = self.config.mpc.train
         if path is None:
-            env_type, env_name = config.env.type, config.env.expert.name
-            path = os.path.join(_MAIN_DIR_PATH,
-                                f"expert_trajectories/{env_type}/{env_name}/trajectories.json")
-        self.expert_trajectories = self.get_expert_trajectories(
-            path=path, num_trajectories=config.mpc.train.num_trajectories,
-            trajectory_len=config.mpc.train.trajectory_len)
-        self.normalizer.update(state_dataset=self.expert_trajectories["states"],
-                               action_dataset=self.expert_trajectories["actions"])
-        rewards = np.sum(self.expert_trajectories["rewards"], axis=1)
-        print(f"Expert trajectories reward mean: {np.mean(rewards):.3f} "
-              f"and reward std: {np.std(rewards):.3f}")
+            env = self.config.env
+            path = os.path.join(_MAIN_DIR_PATH, "expert_trajectories", env.type, env.expert.name,
+                                "trajectories.json")
+        trajs = self.get_expert_trajectories(path=path, num_trajectories=train_cfg.num_trajectories,
+                                             trajectory_len=train_cfg.trajectory_len)
+        self.expert_trajectories = trajs
+        self.normalizer.update(state_dataset=trajs["states"], action_dataset=trajs["actions"])
+        returns = np.sum(trajs["rewards"], axis=1)
+        print(f"Expert trajectories reward mean: {np.mean(returns):.3f} "
+              f"and reward std: {np.std(returns):.3f}")
         return self
 
-    def shuffle_and_split_dataset(self, dataset, key, train_split=0.8):
-        size = dataset[0].shape[0]
-        cut = int(size * train_split)
-        perm = _rng(key).permutation(size)
-        return (tuple(d[perm[:cut]] for d in dataset), tuple(d[perm[cut:]] for d in dataset))
-
-    def _require_init(self):
+    def _trajectories(self):
         if self.expert_trajectories is None:
             raise Exception("Please call init before calling get_cost_dataset.")
+        return self.expert_trajectories
 
+    # ---- splitting -------------------------------------------------------------------------------
+    def shuffle_and_split_dataset(self, dataset, key, train_split=0.8):
+        count = dataset[0].shape[0]
+        order = _generator(key).permutation(count)
+        head, tail = order[:int(count * train_split)], order[int(count * train_split):]
+        return tuple(d[head] for d in dataset), tuple(d[tail] for d in dataset)
+
+    # ---- windows ---------------------------------------------------------------------------------
     def get_cost_dataset(self, key):
-        """X = history+1 states ending at step i (zero-padded before the start), Y = the next
-        horizon+1 states from i, for i in [history, len - horizon) (reference :68-91)."""
-        self._require_init()
-        s_trajs = self.normalizer.normalize_state(self.expert_trajectories["states"])
+        """reference :68-91: for i in [history, len - horizon) of the zero-padded trajectory,
+        X = padded[i-history : i+1], Y = padded[i : i+horizon+1]."""
+        trajs = self._trajectories()
+        states = self.normalizer.normalize_state(trajs["states"])
         horizon, history = self.config.mpc.horizon, self.config.mpc.history
-        X, Y = [], []
-        for s_traj in s_trajs:
-            traj_len, xsize = s_traj.shape
-            count = traj_len - horizon - history
-            padded = np.concatenate([np.zeros((history, xsize)), s_traj], axis=0)
-            X.append(sliding_windows(padded, history + 1, count, start=0))
-            Y.append(sliding_windows(padded, horizon + 1, count, start=history))
-        return self.shuffle_and_split_dataset((np.concatenate(X, 0), np.concatenate(Y, 0)), key)
 
-    def get_dynamics_dataset(self, key):
-        train_dataset, _ = self.get_expert_dataset(key, seqlen=self.config.mpc.horizon)
-        return train_dataset
+        def cut(traj):
+            padded = np.concatenate([np.zeros((history, traj.shape[1])), traj], axis=0)
+            count = traj.shape[0] - horizon - history
+            return (sliding_windows(padded, history + 1, count, start=0),
+                    sliding_windows(padded, horizon + 1, count, start=history))
+
+        return self.shuffle_and_split_dataset(_stack([cut(t) for t in states]), key)
 
     def get_expert_dataset(self, key, seqlen=None):
-        self._require_init()
-        s_trajs, a_trajs = self.normalizer.normalize(
-            state_dataset=self.expert_trajectories["states"],
-            action_dataset=self.expert_trajectories["actions"])
+        trajs = self._trajectories()
+        states, actions = self.normalizer.normalize(state_dataset=trajs["states"],
+                                                    action_dataset=trajs["actions"])
         seqlen = seqlen or self.config.expert_prediction.train.seqlen
-        X, U, Y = [], [], []
-        for s_traj, a_traj in zip(s_trajs, a_trajs):
+
+        def cut(s_traj, a_traj):
             count = s_traj.shape[0] - seqlen
-            X.append(sliding_windows(s_traj, seqlen, count))
-            U.append(sliding_windows(a_traj, seqlen, count))
-            Y.append(sliding_windows(s_traj, seqlen, count, start=1))
-        return self.shuffle_and_split_dataset(
-            (np.concatenate(X, 0), np.concatenate(U, 0), np.concatenate(Y, 0)), key)
+            return (sliding_windows(s_traj, seqlen, count), sliding_windows(a_traj, seqlen, count),
+                    sliding_windows(s_traj, seqlen, count, start=1))
+
+        return self.shuffle_and_split_dataset(_stack([cut(s, a) for s, a in zip(states, actions)]), key)
+
+    def get_dynamics_dataset(self, key):
+        train_split, _ = self.get_expert_dataset(key, seqlen=self.config.mpc.horizon)
+        return train_split
