@@ -256,6 +256,7 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
     if (!rc) rc = dalloc(c, &c->lsw.item_k[i], GMPC_LS_ITEMS * B);
   }
   if (!rc) rc = dalloc(c, &c->lsw.first, B);
+  if (!rc) rc = dalloc(c, &c->lsw.slot, GMPC_LS_ITEMS * B);
   if (!rc) rc = dalloc(c, &c->lsw.cnt, B);
   if (!rc) rc = dalloc(c, &c->lsw.kfirst, B);
   if (!rc) rc = dalloc(c, &c->lsw.prevk, B);

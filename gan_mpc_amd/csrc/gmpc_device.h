@@ -198,8 +198,9 @@ struct TrajArgs {
 // device workspace of the round-based line search (gmpc_traj.hip)
 struct LsWork {
   int* item_b[2]; int* item_k[2];   // ping-pong work lists [maxB * GMPC_LS_ITEMS]
-  int* first; int* cnt; int* kfirst;   // [maxB] this round's candidates of trajectory b: items
-                                       // first .. first+cnt-1 = halvings kfirst .. kfirst+cnt-1
+  int* first; int* cnt; int* kfirst;   // [maxB] this round's candidates of trajectory b: cnt halvings
+                                       // kfirst .. kfirst+cnt-1; candidate j is item slot[b*8 + j]
+  int* slot;                           // [maxB * GMPC_LS_ITEMS]
   int* prevk;                       // [maxB] halving count accepted by the previous line search
   int* counts;                      // [GMPC_LS_ROUNDS_MAX + 1] items per round
   int* run;                         // [maxB]

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
   // the two small weight matrices live in LDS for the whole horizon when they fit (launcher decides)
   float* const w0_s = reinterpret_cast<float*>(xcur + a.n);
   float* const wl_s = w0_s + a.sw0;
-  __shared__ float s_alpha[GMPC_TB];
-  __shared__ int s_bi[GMPC_TB], s_in[GMPC_TB];
+  __shared__ float s_alpha[GMPC_TB], s_oo[GMPC_TB];
+  __shared__ int s_bi[GMPC_TB], s_in[GMPC_TB], s_live[GMPC_TB];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = a.n, m = a.m, T = a.T;
@@ -125,6 +125,12 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
       float al = a.alpha_0;
       for (int k = a.item_k[it]; k > 0; --k) al *= 0.5f;
       s_alpha[tid] = al;
+      // the objective to beat: stage and terminal costs are non-negative, so a candidate whose
+      // running sum has reached it can no longer be accepted (NaN compares false: dead as well)
+      float oo = a.obj[s_bi[tid]];
+      if (isnan(oo)) oo = INFINITY;
+      s_oo[tid] = oo;
+      s_live[tid] = s_in[tid];
     }
   } else if (tid < GMPC_TB) {
     s_bi[tid] = min(b0 + tid, a.B - 1);
@@ -181,7 +187,11 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
 #define TS_(i)
 #endif
 
+    bool aborted = false;
     for (int t = 0; t < T; ++t) {
+      // line search: stop as soon as none of the four candidates can still be accepted (flags of the
+      // previous step's cost evaluation; the barriers of that step ordered them)
+      if (LS && t > 0 && (s_live[0] | s_live[1] | s_live[2] | s_live[3]) == 0) { aborted = true; break; }
       // ---- controls and layer-0 input
       for (int i = tid; i < n; i += blockDim.x) actA[i] = xcur[i];
       if (LS) {
@@ -240,6 +250,7 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
         const float al = GMPC_ALPHA;
         const float cst = w0 * (sqrtf(uu + al * al) - al) + w1 * (sqrtf(dd + al * al) - al);
         objacc += cst;
+        if (LS && lane == 0) s_live[c] = (INB(c) && objacc < s_oo[c]) ? 1 : 0;
         if (!LS && lane == 0 && INB(c) && a.costs) a.costs[(size_t)bc * (T + 1) + t] = cst;
       }
       TS_(1)
@@ -290,6 +301,10 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
       printf("tid %d: staging %llu cost %llu L0 %llu L1 %llu L2 %llu out %llu (cycles per step)\n", tid,
              st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T, st_[6] / T);
 #endif
+    if (LS && aborted) {
+      if (tid < GMPC_TB && INB(tid)) a.objc[CI(tid)] = INFINITY;     // rejected without a full rollout
+      return;
+    }
     // ---- terminal cost w2 * |cost_mlp(x_T)|^2
     {
       float4* in = xcur;
@@ -342,10 +357,11 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
 #define GMPC_LS_NEXT 4   // candidates queued per trajectory after a round without an accepted step
 
 __global__ void k_ls_init(int B, const int* active, float alpha_0, float alpha_min, int k_max, int* iters,
-                          int* run, int* item_b, int* item_k, int* first, int* cnt, int* kfirst,
-                          const int* prevk, int* count, float* alpha, float* U_step, float* obj_step) {
+                          int* run, int* cnt, int* kfirst, const int* prevk, float* alpha, float* U_step,
+                          float* obj_step) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  cnt[b] = 0;
   if (active != nullptr && active[b] == 0) { run[b] = 0; return; }
   iters[b] += 1;
   if (alpha_0 > alpha_min) {
@@ -354,9 +370,6 @@ __global__ void k_ls_init(int B, const int* active, float alpha_0, float alpha_m
     R = R > GMPC_LS_ITEMS ? GMPC_LS_ITEMS : R;
     R = R > k_max ? k_max : R;
     run[b] = 1;
-    const int pos = atomicAdd(count, R);
-    for (int j = 0; j < R; ++j) { item_b[pos + j] = b; item_k[pos + j] = j; }
-    first[b] = pos;
     cnt[b] = R;
     kfirst[b] = 0;
   } else {
@@ -367,14 +380,46 @@ __global__ void k_ls_init(int B, const int* active, float alpha_0, float alpha_m
   }
 }
 
+// Work list of a round, ordered by candidate number first and trajectory second: the four slots of a
+// k_traj<true> workgroup then hold the SAME halving count of four trajectories.  Large steps are
+// rejected early in the horizon (their running cost passes the objective to beat within a few
+// steps), and a workgroup whose four candidates are all dead stops -- which only happens when
+// candidates of similar fate sit together.  One workgroup; cnt[b] candidates for trajectory b.
+__global__ __launch_bounds__(1024) void k_ls_place(int B, const int* cnt, const int* kfirst, int* item_b,
+                                                   int* item_k, int* slot, int* count) {
+  __shared__ int s_n[GMPC_LS_ITEMS], s_base[GMPC_LS_ITEMS], s_fill[GMPC_LS_ITEMS];
+  const int tid = threadIdx.x;
+  if (tid < GMPC_LS_ITEMS) { s_n[tid] = 0; s_fill[tid] = 0; }
+  __syncthreads();
+  for (int b = tid; b < B; b += blockDim.x) {
+    const int c = cnt[b];
+    for (int j = 0; j < c; ++j) atomicAdd(&s_n[j], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int j = 0; j < GMPC_LS_ITEMS; ++j) { s_base[j] = acc; acc += s_n[j]; }
+    *count = acc;
+  }
+  __syncthreads();
+  for (int b = tid; b < B; b += blockDim.x) {
+    const int c = cnt[b], k0 = kfirst[b];
+    for (int j = 0; j < c; ++j) {
+      const int pos = s_base[j] + atomicAdd(&s_fill[j], 1);
+      item_b[pos] = b;
+      item_k[pos] = k0 + j;
+      slot[b * GMPC_LS_ITEMS + j] = pos;
+    }
+  }
+}
+
 struct LsDecideArgs {
   int n, m, T, Lh, k_max;
   float alpha_0;
-  int* first; int* cnt; int* kfirst; int* prevk; int* run;
+  const int* slot; int* cnt; int* kfirst; int* prevk; int* run;
   const float* objc; const float* Xc; const float* Uc; const uint32_t* maskc;
   float* X; float* U; uint32_t* masks;
   float* obj; float* obj_step; float* U_step; float* alpha;
-  int* next_item_b; int* next_item_k; int* next_count;
 };
 
 __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
@@ -382,8 +427,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
   if (a.run[b] == 0) return;
   __shared__ int s_acc;
   __shared__ float s_us[GMPC_THREADS / 64];
-  const int f = a.first[b];
-  __syncthreads();            // first[b] is rewritten by thread 0 below
+  const int* sl = a.slot + (size_t)b * GMPC_LS_ITEMS;
+  __shared__ int s_item;
   if (tid == 0) {
     float oo = a.obj[b];
     if (isnan(oo)) oo = INFINITY;
@@ -391,10 +436,11 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
     int acc = -1;
     float on_acc = 0.f;
     for (int j = 0; j < R; ++j) {
-      float on = a.objc[f + j];
+      float on = a.objc[sl[j]];
       if (isnan(on)) on = oo;
       if (on < oo) { acc = j; on_acc = on; break; }
     }
+    s_item = acc >= 0 ? sl[acc] : 0;
     auto halved = [&](int k) { float al = a.alpha_0; for (; k > 0; --k) al *= 0.5f; return al; };
     if (acc >= 0) {
       a.obj[b] = on_acc;
@@ -402,19 +448,17 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
       a.alpha[b] = halved(k0 + acc + 1);
       a.prevk[b] = k0 + acc;
       a.run[b] = 0;
+      a.cnt[b] = 0;
     } else if (k0 + R >= a.k_max) {      // every step size down to alpha_min failed
       a.alpha[b] = halved(a.k_max);
       a.U_step[b] = 0.f;
       a.obj_step[b] = 0.f;
       a.prevk[b] = a.k_max - 1;
       a.run[b] = 0;
-    } else {
+      a.cnt[b] = 0;
+    } else {                               // queue the next GMPC_LS_NEXT halvings (k_ls_place)
       const int left = a.k_max - (k0 + R);
-      const int nr = left < GMPC_LS_NEXT ? left : GMPC_LS_NEXT;
-      const int pos = atomicAdd(a.next_count, nr);
-      for (int j = 0; j < nr; ++j) { a.next_item_b[pos + j] = b; a.next_item_k[pos + j] = k0 + R + j; }
-      a.first[b] = pos;
-      a.cnt[b] = nr;
+      a.cnt[b] = left < GMPC_LS_NEXT ? left : GMPC_LS_NEXT;
       a.kfirst[b] = k0 + R;
     }
     s_acc = acc;
@@ -422,8 +466,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
   __syncthreads();
   const int acc = s_acc;
   if (acc < 0) return;
-  // commit candidate f + acc as the new iterate
-  const size_t it = (size_t)(f + acc);
+  // commit the accepted candidate as the new iterate
+  const size_t it = (size_t)s_item;
   const int n = a.n, m = a.m, T = a.T;
   float* Xd = a.X + (size_t)b * (T + 1) * n;
   const float* Xs = a.Xc + it * (T + 1) * n;
@@ -530,24 +574,23 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s) {
   // worst case: a first round of one candidate, then GMPC_LS_NEXT per round
   const int rounds = k_max > 0 ? 1 + (k_max - 1 + GMPC_LS_NEXT - 1) / GMPC_LS_NEXT : 0;
   if (rounds > GMPC_LS_ROUNDS_MAX) return -1;
-  if (hipMemsetAsync(w.counts, 0, (GMPC_LS_ROUNDS_MAX + 1) * sizeof(int), s) != hipSuccess) return -2;
   hipLaunchKernelGGL(k_ls_init, dim3((a.B + 255) / 256), dim3(256), 0, s, a.B, a.active, a.alpha_0,
-                     a.alpha_min, k_max, a.iters, w.run, w.item_b[0], w.item_k[0], w.first, w.cnt, w.kfirst,
-                     w.prevk, w.counts, a.alpha, a.U_step, a.obj_step);
+                     a.alpha_min, k_max, a.iters, w.run, w.cnt, w.kfirst, w.prevk, a.alpha, a.U_step,
+                     a.obj_step);
   for (int r = 0; r < rounds; ++r) {
-    const int cur = r & 1, nxt = cur ^ 1;
-    a.item_b = w.item_b[cur]; a.item_k = w.item_k[cur]; a.nitems = w.counts + r; a.objc = w.objc;
+    hipLaunchKernelGGL(k_ls_place, dim3(1), dim3(1024), 0, s, a.B, w.cnt, w.kfirst, w.item_b[0], w.item_k[0],
+                       w.slot, w.counts + r);
+    a.item_b = w.item_b[0]; a.item_k = w.item_k[0]; a.nitems = w.counts + r; a.objc = w.objc;
     const long max_items = (long)a.B * (r == 0 ? GMPC_LS_ITEMS : GMPC_LS_NEXT);
     hipLaunchKernelGGL(k_traj<true>, dim3((unsigned)((max_items + GMPC_TB - 1) / GMPC_TB)),
                        dim3(GMPC_TRAJ_THREADS), lds, s, a);
     LsDecideArgs d;
     d.n = a.n; d.m = a.m; d.T = a.T; d.Lh = a.dyn.L - 1; d.k_max = k_max;
     d.alpha_0 = a.alpha_0;
-    d.first = w.first; d.cnt = w.cnt; d.kfirst = w.kfirst; d.prevk = w.prevk; d.run = w.run;
+    d.slot = w.slot; d.cnt = w.cnt; d.kfirst = w.kfirst; d.prevk = w.prevk; d.run = w.run;
     d.objc = w.objc; d.Xc = a.Xc; d.Uc = a.Uc; d.maskc = a.maskc;
     d.X = a.X; d.U = a.Uio; d.masks = a.masks;
     d.obj = a.obj; d.obj_step = a.obj_step; d.U_step = a.U_step; d.alpha = a.alpha;
-    d.next_item_b = w.item_b[nxt]; d.next_item_k = w.item_k[nxt]; d.next_count = w.counts + r + 1;
     hipLaunchKernelGGL(k_ls_decide, dim3(a.B), dim3(GMPC_THREADS), 0, s, d);
   }
   return 0;
