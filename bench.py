@@ -160,18 +160,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import gan_mpc_oracle as orc  # synthetic-problem generator only (inputs), never in the timed path
     from gan_mpc_amd import params as P
+    from gan_mpc_amd import synthetic
     from gan_mpc_amd.engine import Engine
 
     w = dict(WORKLOADS[args.workload])
     B = args.batch or w["B"]
     n, m, T, F = w["n"], w["m"], w["T"], w["F"]
-    pb = orc.make_problem(n, m, T, B, seed=1000 + rank, dyn_hidden=w["dyn_hidden"],
+    pb = synthetic.make_problem(n, m, T, B, seed=1000 + rank, dyn_hidden=w["dyn_hidden"],
                           cost_hidden=w["cost_hidden"], cost_fout=w["cost_fout"], lstm_features=F,
                           head_hidden=w["head_hidden"])
-    wts = orc.make_problem(n, m, T, 1, seed=0, dyn_hidden=w["dyn_hidden"], cost_hidden=w["cost_hidden"],
+    wts = synthetic.make_problem(n, m, T, 1, seed=0, dyn_hidden=w["dyn_hidden"], cost_hidden=w["cost_hidden"],
                            cost_fout=w["cost_fout"], lstm_features=F, head_hidden=w["head_hidden"])
     dyn_dims = [n + m, *w["dyn_hidden"], n]
     cost_dims = [n, *w["cost_hidden"], w["cost_fout"]]
@@ -182,7 +181,7 @@ def main():
     # identical (seed 0) parameters on every rank, rank-specific trajectories
     eng.set_params(d(wts["mpc_w"]), d(P.pack_mlp(P.layers_to_tree(wts["dyn"]))),
                    d(P.pack_mlp(P.layers_to_tree(wts["cmlp"]))))
-    critic = d(P.pack_critic(P.critic_oracle_to_tree(wts["critic"])))
+    critic = d(P.pack_critic(P.critic_dict_to_tree(wts["critic"])))
     adam_m, adam_v = torch.zeros_like(critic), torch.zeros_like(critic)
     x0, U, goal = d(pb["x0"]), d(pb["U"]), d(pb["goal"])
     xseq = eng.new(2 * B, T + 1, n)

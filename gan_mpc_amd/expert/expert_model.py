@@ -110,7 +110,7 @@ class ExpertModel(ExpertProtocol):
             sizes = [ywidth] + [mdl.num_hidden_units] * (L - 1) + [out]
             ex[key] = [(nn_init.lecun_normal(rng, a, b), np.zeros(b, np.float32))
                        for a, b in zip(sizes[:-1], sizes[1:])]
-        return P.expert_oracle_to_tree(ex)
+        return P.expert_dict_to_tree(ex)
 
     def _device_params(self, expert_params, engine):
         from gan_mpc_amd.engine import make_expert_shape

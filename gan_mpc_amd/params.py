@@ -119,8 +119,8 @@ def unpack_critic(flat, n, F, head_dims, scope=LSTM_SCOPE):
     return {"params": p}
 
 
-def critic_oracle_to_tree(cr, scope=LSTM_SCOPE):
-    """dict(Wx, Wh, b, head) (the layout the tests' oracle uses) -> flax tree."""
+def critic_dict_to_tree(cr, scope=LSTM_SCOPE):
+    """dict(Wx, Wh, b, head) (plain arrays: Wx, Wh, b, head) -> flax tree."""
     F = cr["Wh"].shape[0]
     cell = {}
     for gi, g in enumerate(GATES):
@@ -133,7 +133,7 @@ def critic_oracle_to_tree(cr, scope=LSTM_SCOPE):
     return {"params": p}
 
 
-def critic_tree_to_oracle(tree):
+def critic_tree_to_dict(tree):
     p = tree["params"]
     cell = p[_lstm_scope(p)]
     Wx = np.concatenate([np.asarray(cell["i" + g]["kernel"]) for g in GATES], axis=1)
@@ -179,7 +179,7 @@ def _find_scope(tree, pred):
     return None
 
 
-def expert_tree_to_oracle(tree):
+def expert_tree_to_dict(tree):
     cell = _find_scope(tree, lambda d: any(k.startswith("MLPCell") for k in d))
     if cell is None:
         raise KeyError("no MLPCell scopes in expert params")
@@ -196,7 +196,7 @@ def expert_tree_to_oracle(tree):
     return ex
 
 
-def expert_oracle_to_tree(ex, scope=EXPERT_CELL_SCOPE):
+def expert_dict_to_tree(ex, scope=EXPERT_CELL_SCOPE):
     cell = {}
     if "lstm" in ex:
         F = ex["lstm"]["Wh"].shape[0]
@@ -215,10 +215,10 @@ def expert_oracle_to_tree(ex, scope=EXPERT_CELL_SCOPE):
 
 
 def pack_expert(ex):
-    """oracle-style dict (or a tree) -> (flat fp32 vector, lstm_features, head_dims_x, head_dims_u) in
+    """plain dict of arrays (or a tree) -> (flat fp32 vector, lstm_features, head_dims_x, head_dims_u) in
     the layout of gmpc_expert_rollout."""
     if "params" in ex:
-        ex = expert_tree_to_oracle(ex)
+        ex = expert_tree_to_dict(ex)
     parts = []
     if "lstm" in ex:
         F = ex["lstm"]["Wh"].shape[0]

@@ -51,7 +51,7 @@ def engine_for(pb, max_batch=None, critic=True):
 
 
 def critic_flat(pb):
-    return P.pack_critic(P.critic_oracle_to_tree(pb["critic"]))
+    return P.pack_critic(P.critic_dict_to_tree(pb["critic"]))
 
 
 def near_kink(layers, q, thresh=3e-6):

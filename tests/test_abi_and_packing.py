@@ -80,14 +80,14 @@ def test_mlp_pack_roundtrip():
 
 def test_critic_pack_roundtrip_and_gate_order():
     pb = orc.make_problem(5, 2, 4, 3, seed=2, lstm_features=8, head_hidden=(6,), bias_scale=0.5)
-    tree = P.critic_oracle_to_tree(pb["critic"])
+    tree = P.critic_dict_to_tree(pb["critic"])
     cell = tree["params"][P.LSTM_SCOPE]
     assert set(cell) == {"ii", "if", "ig", "io", "hi", "hf", "hg", "ho"}
     assert "bias" not in cell["ii"] and "bias" in cell["hi"]
     flat = P.pack_critic(tree)
     n, F, head = P.critic_dims(tree)
     assert (n, F, head) == (5, 8, [8, 6, 1])
-    back = P.critic_tree_to_oracle(P.unpack_critic(flat, n, F, head))
+    back = P.critic_tree_to_dict(P.unpack_critic(flat, n, F, head))
     for k in ("Wx", "Wh", "b"):
         np.testing.assert_array_equal(back[k], pb["critic"][k])
     # forget-gate block sits second: columns F..2F of Wx

@@ -53,7 +53,7 @@ def _oracle_problem(params, data, idx, dtype):
               goal=data["goal"][idx], x0=data["hist"][idx, -1], U=data["init_U"][idx],
               true_seq=data["Y"][idx])
     if "critic_params" in params:
-        pb["critic"] = P.critic_tree_to_oracle(params["critic_params"])
+        pb["critic"] = P.critic_tree_to_dict(params["critic_params"])
     return orc.cast_problem(pb, dtype)
 
 
@@ -108,7 +108,7 @@ def test_critic_loss_and_grad_is_batch_mean():
     xs = data["Y"][:10]
     lab = np.array([1, -1] * 5, np.float32)
     loss, grads = policy.critic_loss_and_grad(xs, lab, params)
-    cr = P.critic_tree_to_oracle(params["critic_params"])
+    cr = P.critic_tree_to_dict(params["critic_params"])
     l32, g32 = orc.critic_loss_and_grad(cr, xs, lab)
     cr64 = orc.cast_problem(dict(c=cr), np.float64)["c"]
     l64, g64 = orc.critic_loss_and_grad(cr64, xs.astype(np.float64), lab.astype(np.float64))
@@ -218,7 +218,7 @@ def test_policy_with_the_expert_sequence_model():
     rng = np.random.default_rng(1)
     hist = rng.standard_normal((6, config.mpc.history + 1, N)).astype(np.float32)
     goal, init_U = policy.get_goal_states_init_actions(hist, params)
-    ex = P.expert_tree_to_oracle(params["expert_params"])
+    ex = P.expert_tree_to_dict(params["expert_params"])
     g64, u64 = orc.expert_goal_states_init_actions(orc.cast_problem(dict(e=ex), np.float64)["e"],
                                                    hist.astype(np.float64), config.mpc.horizon)
     assert gu.rel_err(goal.cpu().numpy(), g64) < 1e-5 and gu.rel_err(init_U.cpu().numpy(), u64) < 1e-5

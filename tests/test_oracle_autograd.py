@@ -307,7 +307,7 @@ def test_expert_rollout_matches_torch_cells(kind):
             np.testing.assert_allclose(U[b], torch.stack(us).numpy(), rtol=1e-10, atol=1e-12)
     # packing round trip through the flax-style tree
     from gan_mpc_amd import params as P
-    flat, Fp, dx, du = P.pack_expert(P.expert_oracle_to_tree(ex))
+    flat, Fp, dx, du = P.pack_expert(P.expert_dict_to_tree(ex))
     flat2, *_ = P.pack_expert(ex)
     np.testing.assert_array_equal(flat, flat2)
     assert Fp == (F if kind == "lstm" else 0) and dx[-1] == n and du[-1] == m
