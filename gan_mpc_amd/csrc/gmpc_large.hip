@@ -196,12 +196,15 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
     }
 }
 
+#ifndef GMPC_BG_KC
+#define GMPC_BG_KC 8
+#endif
 template <int WMT, int WNT>
 static void launch_lds(const BgemmArgs& a, hipStream_t s) {
   constexpr int BM = 64 * WMT, BN = 64 * WNT;
   const long total = (long)a.batch * ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const long per = (total + 7) / 8;
-  hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT, 8>), dim3((unsigned)(per * 8)), dim3(GMPC_THREADS), 0, s, a);
+  hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT, GMPC_BG_KC>), dim3((unsigned)(per * 8)), dim3(GMPC_THREADS), 0, s, a);
 }
 
 void gmpc_launch_bgemm_tn(const BgemmArgs& a, hipStream_t s) {
