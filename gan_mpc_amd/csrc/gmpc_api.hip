@@ -277,7 +277,8 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
     B_(PAB, B * n * nm + pad);
     B_(T1, B * n * n + pad);
     B_(HG, B * m * nm + pad);
-    B_(W, B * m * n + pad);
+    B_(KV, 2 * B * m * n + pad);
+    B_(VK, 2 * B * m * n + pad);
     B_(pvec, B * n); B_(lam, B * n); B_(sbuf, B); B_(gn2, B);
 #undef B_
     c->AB = c->bw.ABt;

@@ -269,12 +269,13 @@ struct BgemmArgs {
   const float* X2 = nullptr; long sx2 = 0; int ldx2 = 0;
   const float* Y2 = nullptr; long sy2 = 0; int ldy2 = 0;
   int K2 = 0;
+  int upper_only = 0;   // square symmetric result: skip the blocks that lie entirely below the diagonal
 };
 
 // workspace of the large-state backward pass (gmpc_large.hip)
 struct BigWork {
   int n, m, T;
-  float *ABt, *P, *PAB, *T1, *HG, *W, *pvec, *lam, *sbuf, *gn2;
+  float *ABt, *P, *PAB, *T1, *HG, *KV, *VK, *pvec, *lam, *sbuf, *gn2;
 };
 
 // zero-padded weight copies read by the MFMA Jacobian chain (gmpc_linearize_mfma.hip)

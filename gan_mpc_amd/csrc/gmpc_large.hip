@@ -7,10 +7,15 @@
 //     [A_t | B_t]  <- MFMA Jacobian chain on the samples (b, t)          (k_linearize_mfma, strided)
 //     [PA | PB] = P [A | B]                 batched fp32-MFMA GEMMs      (k_bgemm_tn_lds / k_bgemm_tn)
 //     [H | Gr]  = B^T [PA | PB]                                          (k_bgemm_tn)
-//     gains K_t k_t, adjoint, value vector, W = H + (H + G K)            (k_big_step)
-//     T1 = A^T (PA) + K^T W     one GEMM over two K-segments             (k_bgemm_tn_lds)
-//     P <- Q_t + sym(T1)                                                 (k_big_pupdate)
-// sym(K^T W) equals sym((H+GK)^T K + K^T H), the cross terms of trajax' lqr_step value update.
+//     gains K_t k_t, adjoint, value vector, V = H + G K / 2               (k_big_step)
+//     T1 = A^T (PA) + K^T V + V^T K   one GEMM over two K-segments, only the blocks that touch the
+//                                     upper triangle                     (k_bgemm_tn_lds)
+//     P <- Q_t + T1 (upper triangle, mirrored)                           (k_big_pupdate)
+// K^T V + V^T K = K^T H + H^T K + K^T G K are the cross terms of trajax' lqr_step value update; written
+// as [K; V]^T [V; K] the product is symmetric term by term, so -- like A^T P A with a symmetric P -- its
+// two triangles differ only by rounding and the lower one need not be computed (half of the second
+// n^3 product of every step).  trajax symmetrises the sum explicitly; the mirror gives the same
+// exactly symmetric P up to that rounding.
 // Every product is written as  C = sum_k X[k][:]^T Y[k][:]  ("TN") with row-major operands, so row k
 // of X / Y IS the MFMA A / B operand of k-step k and all global reads are coalesced; P's symmetry
 // turns P A into that form (X = P).  Reference arithmetic: trajax lqr_step / tvlqr / adjoint.
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
   const int mi = rem / nb, ni = rem - mi * nb;
   if (a.active != nullptr && a.active[b] == 0) return;
   const int m0 = mi * BM, n0 = ni * BN;
+  if (a.upper_only && m0 > n0 + BN - 1) return;     // no element with row <= column in this block
   f32x16 acc[WMT][WNT];
 #pragma unroll
   for (int i = 0; i < WMT; ++i)
@@ -252,7 +258,8 @@ struct BigStepArgs {
   const float* X; const float* U; const float* goal; const float* mpc_w;
   const float* ABt;      // [B][n][n+m]   Jacobians of step t
   const float* HG;       // [B][m][n+m]   [B^T P A | B^T P B]
-  float* W;              // [B][m][n]     out: H + (H + G K)
+  float* KV;             // [B][2m][n]    out: rows 0..m-1 = K_t, rows m..2m-1 = V = H + G K / 2
+  float* VK;             // [B][2m][n]    out: rows 0..m-1 = V,   rows m..2m-1 = K_t
   float* pvec; float* lam;   // [B][n]    value vector / adjoint, updated in place
   float* sbuf;           // [B]           out: sqrt(|x-g|^2 + alpha^2) of this step (for Q_t)
   float* gn2;            // [B]           running sum of squared control gradients
@@ -381,7 +388,8 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   }
   __syncthreads();
   float* Kt = a.K + bt * m * n;
-  float* W = a.W + (size_t)b * m * n;
+  float* KV = a.KV + (size_t)b * 2 * m * n;
+  float* VK = a.VK + (size_t)b * 2 * m * n;
   float* y = ycol + tid;
   if (!m1) {
     // Cholesky of G + 1e-8 I in L (lower), column by column; NaN on a non-positive pivot
@@ -471,13 +479,18 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
       }
     }
   }
-  // W = H + (H + G K) for the thread's own columns (K column read back from its own writes)
+  // V = H + G K / 2 and the stacked operands [K; V], [V; K] of the cross-term product, for the
+  // thread's own columns (K column read back from its own writes)
   for (int c = tid; c < n; c += blockDim.x) {
     for (int i = 0; i < m; ++i) {
       float v = 0.f;
       for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], Kt[(size_t)k * n + c], v);
-      const float hic = HG[(size_t)i * nm + c];
-      W[(size_t)i * n + c] = hic + (hic + v);
+      const float vic = fmaf(0.5f, v, HG[(size_t)i * nm + c]);
+      const float kic = Kt[(size_t)i * n + c];
+      KV[(size_t)i * n + c] = kic;
+      KV[(size_t)(m + i) * n + c] = vic;
+      VK[(size_t)i * n + c] = vic;
+      VK[(size_t)(m + i) * n + c] = kic;
     }
   }
   __syncthreads();
@@ -498,13 +511,14 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   }
 }
 
-// P = Q_t + (T1 + T1^T)/2 for the tile pair (I, J), (J, I): both tiles are read row-wise and meet
-// through LDS, so every global access is coalesced and P comes out exactly symmetric.
+// P = Q_t + T1 on the upper triangle, mirrored into the lower one: tile (I, J) with I <= J is read
+// row-wise once and written twice (the transposed copy through LDS), so every global access is
+// coalesced and P comes out exactly symmetric.  T1's strictly lower blocks are never read.
 __global__ __launch_bounds__(GMPC_THREADS) void k_big_pupdate(int n, int T, int t, const float* X,
                                                               const float* goal, const float* mpc_w,
                                                               const float* sbuf, const float* T1,
                                                               const int* active, float* P) {
-  __shared__ float tA[32][33], tB[32][33], dI[32], dJ[32];
+  __shared__ float tA[32][33], dI[32], dJ[32];
   const int I = blockIdx.y, J = blockIdx.x, b = blockIdx.z;
   if (I > J) return;
   if (active != nullptr && active[b] == 0) return;
@@ -518,30 +532,27 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_pupdate(int n, int T, int 
     const int j = J * 32 + tx;
     dJ[tx] = j < n ? X[xb + j] - goal[xb + j] : 0.f;
   }
-  for (int r = ty; r < 32; r += 8) {
-    const int ia = I * 32 + r, ja = J * 32 + tx;
-    tA[r][tx] = (ia < n && ja < n) ? T1[o + (size_t)ia * n + ja] : 0.f;
-    const int ib = J * 32 + r, jb = I * 32 + tx;
-    tB[r][tx] = (ib < n && jb < n) ? T1[o + (size_t)ib * n + jb] : 0.f;
-  }
   __syncthreads();
   const float w1 = sigmoidf_(mpc_w[1]);
   const float s = sbuf[b];
   const float is = 1.f / s, is3 = 1.f / (s * s * s);
   for (int r = ty; r < 32; r += 8) {
-    {
-      const int i = I * 32 + r, j = J * 32 + tx;
-      if (i < n && j < n) {
-        const float Q = w1 * ((i == j ? is : 0.f) - dI[r] * dJ[tx] * is3);
-        P[o + (size_t)i * n + j] = Q + (tA[r][tx] + tB[tx][r]) * 0.5f;
-      }
+    const int i = I * 32 + r, j = J * 32 + tx;
+    float v = 0.f;
+    if (i < n && j < n) {
+      // diagonal tiles: take the element of the upper triangle for both (i, j) and (j, i)
+      const size_t src = i <= j ? (size_t)i * n + j : (size_t)j * n + i;
+      const float di = dI[r], dj = dJ[tx];
+      v = w1 * ((i == j ? is : 0.f) - di * dj * is3) + T1[o + src];
+      P[o + (size_t)i * n + j] = v;
     }
-    if (I != J) {
-      const int i = J * 32 + r, j = I * 32 + tx;
-      if (i < n && j < n) {
-        const float Q = w1 * (0.f - dI[tx] * dJ[r] * is3);
-        P[o + (size_t)i * n + j] = Q + (tA[tx][r] + tB[r][tx]) * 0.5f;
-      }
+    tA[r][tx] = v;
+  }
+  __syncthreads();
+  if (I != J) {
+    for (int r = ty; r < 32; r += 8) {
+      const int i = J * 32 + r, j = I * 32 + tx;     // transposed tile
+      if (i < n && j < n) P[o + (size_t)i * n + j] = tA[tx][r];
     }
   }
 }
@@ -632,14 +643,16 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
     BigStepArgs a;
     a.B = B; a.n = n; a.m = m; a.T = T; a.t = t;
     a.mode = lx != nullptr ? 1 : 0; a.lx = lx; a.Bvec = Bvec;
-    a.X = X; a.U = U; a.goal = goal; a.mpc_w = mpc_w; a.ABt = w.ABt; a.HG = w.HG; a.W = w.W;
+    a.X = X; a.U = U; a.goal = goal; a.mpc_w = mpc_w; a.ABt = w.ABt; a.HG = w.HG; a.KV = w.KV; a.VK = w.VK;
     a.pvec = w.pvec; a.lam = w.lam; a.sbuf = w.sbuf; a.gn2 = w.gn2; a.active = active;
     a.K = K; a.k = k; a.grad = grad; a.adj = adj;
     hipLaunchKernelGGL(k_big_step, dim3(B), dim3(GMPC_THREADS), lds, s, a);
-    // T1 = A^T (PA) + K_t^T W
+    // T1 = A^T (PA) + [K; V]^T [V; K], upper blocks only
     BgemmArgs g = gemm(n, n, n, A, snm, nm, w.PAB, snm, nm, w.T1, snn, n);
-    g.X2 = K + (size_t)t * m * n; g.sx2 = (long)T * m * n; g.ldx2 = n;   // K[b][t]
-    g.Y2 = w.W; g.sy2 = smn; g.ldy2 = n; g.K2 = m;
+    g.X2 = w.KV; g.sx2 = 2 * smn; g.ldx2 = n;
+    g.Y2 = w.VK; g.sy2 = 2 * smn; g.ldy2 = n; g.K2 = 2 * m;
+    static const bool full_t1 = getenv("GMPC_BIG_FULL_T1") != nullptr;   // A/B timing only
+    g.upper_only = full_t1 ? 0 : 1;
     gmpc_launch_bgemm_tn(g, s);
     hipLaunchKernelGGL(k_big_pupdate, dim3(nt, nt, B), dim3(GMPC_THREADS), 0, s, n, T, t, X, goal, mpc_w,
                        w.sbuf, w.T1, active, w.P);
