@@ -423,7 +423,19 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
         y[i * GMPC_THREADS] = v / L[i * m + i];
       }
       if (c < n) {
-        for (int i = 0; i < m; ++i) Kt[(size_t)i * n + c] = -y[i * GMPC_THREADS];
+        // K column, V = H + G K / 2 and the stacked operands [K; V], [V; K] of the cross-term product
+        // (the column is still in LDS: no global re-reads)
+        for (int i = 0; i < m; ++i) {
+          float v = 0.f;
+          for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], -y[k * GMPC_THREADS], v);
+          const float kic = -y[i * GMPC_THREADS];
+          const float vic = fmaf(0.5f, v, HG[(size_t)i * nm + c]);
+          Kt[(size_t)i * n + c] = kic;
+          KV[(size_t)i * n + c] = kic;
+          KV[(size_t)(m + i) * n + c] = vic;
+          VK[(size_t)i * n + c] = vic;
+          VK[(size_t)(m + i) * n + c] = kic;
+        }
       } else {
         for (int i = 0; i < m; ++i) { kv[i] = -y[i * GMPC_THREADS]; a.k[bt * m + i] = -y[i * GMPC_THREADS]; }
       }
@@ -473,24 +485,22 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
         y[i * GMPC_THREADS] = v / L[i * m + i];
       }
       if (c < n) {
-        for (int i = 0; i < m; ++i) Kt[(size_t)i * n + c] = -y[i * GMPC_THREADS];
+        // K column, V = H + G K / 2 and the stacked operands [K; V], [V; K] of the cross-term product
+        // (the column is still in LDS: no global re-reads)
+        for (int i = 0; i < m; ++i) {
+          float v = 0.f;
+          for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], -y[k * GMPC_THREADS], v);
+          const float kic = -y[i * GMPC_THREADS];
+          const float vic = fmaf(0.5f, v, HG[(size_t)i * nm + c]);
+          Kt[(size_t)i * n + c] = kic;
+          KV[(size_t)i * n + c] = kic;
+          KV[(size_t)(m + i) * n + c] = vic;
+          VK[(size_t)i * n + c] = vic;
+          VK[(size_t)(m + i) * n + c] = kic;
+        }
       } else {
         for (int i = 0; i < m; ++i) { kv[i] = -y[i * GMPC_THREADS]; a.k[bt * m + i] = -y[i * GMPC_THREADS]; }
       }
-    }
-  }
-  // V = H + G K / 2 and the stacked operands [K; V], [V; K] of the cross-term product, for the
-  // thread's own columns (K column read back from its own writes)
-  for (int c = tid; c < n; c += blockDim.x) {
-    for (int i = 0; i < m; ++i) {
-      float v = 0.f;
-      for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], Kt[(size_t)k * n + c], v);
-      const float vic = fmaf(0.5f, v, HG[(size_t)i * nm + c]);
-      const float kic = Kt[(size_t)i * n + c];
-      KV[(size_t)i * n + c] = kic;
-      KV[(size_t)(m + i) * n + c] = vic;
-      VK[(size_t)i * n + c] = vic;
-      VK[(size_t)(m + i) * n + c] = kic;
     }
   }
   __syncthreads();
