@@ -20,6 +20,8 @@
 // of X / Y IS the MFMA A / B operand of k-step k and all global reads are coalesced; P's symmetry
 // turns P A into that form (X = P).  Reference arithmetic: trajax lqr_step / tvlqr / adjoint.
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 #include "gmpc_device.h"
 
@@ -97,12 +99,17 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bgemm_tn(BgemmArgs a) {
 // Against one-wave strips this cuts the L2 traffic per output ~3x, which is what bounded them.
 // A second K-segment (X2, Y2, K2) is accumulated into the same tile.
 // ------------------------------------------------------------------------------------------------
-template <int WMT, int WNT, int KC>
+// VEC: operands whose leading dimensions, sizes and base addresses are multiples of 4 floats are staged
+// with 16-byte loads and LDS writes (a quarter of the staging instructions).
+template <int WMT, int WNT, int KC, bool VEC = false>
 __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
   constexpr int BM = 64 * WMT, BN = 64 * WNT;
-  constexpr int LX = KC * BM / GMPC_THREADS, LY = KC * BN / GMPC_THREADS;
-  __shared__ float Xs[2][KC][BM];
-  __shared__ float Ys[2][KC][BN];
+  constexpr int VW = VEC ? 4 : 1;
+  constexpr int LX = KC * BM / GMPC_THREADS / VW, LY = KC * BN / GMPC_THREADS / VW;
+  static_assert(!VEC || (KC * BM) % (4 * GMPC_THREADS) == 0 && (KC * BN) % (4 * GMPC_THREADS) == 0, "vec staging");
+  typedef typename std::conditional<VEC, float4, float>::type stage_t;
+  __shared__ __attribute__((aligned(16))) float Xs[2][KC][BM];
+  __shared__ __attribute__((aligned(16))) float Ys[2][KC][BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -126,8 +133,9 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
     for (int j = 0; j < WNT; ++j)
 #pragma unroll
       for (int rg = 0; rg < 16; ++rg) acc[i][j][rg] = 0.f;
-  float rx[LX], ry[LY];
+  stage_t rx[LX], ry[LY];
   const int c1 = (a.K + KC - 1) / KC, c2 = (a.K2 + KC - 1) / KC, nc = c1 + c2;
+  auto zero = []() { stage_t z; memset(&z, 0, sizeof(z)); return z; };
   auto issue = [&](int ci) {
     const bool first = ci < c1;
     const float* X = first ? a.X + (size_t)b * a.sx : a.X2 + (size_t)b * a.sx2;
@@ -136,27 +144,27 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
     const int K = first ? a.K : a.K2, k0 = (first ? ci : ci - c1) * KC;
 #pragma unroll
     for (int j = 0; j < LX; ++j) {
-      const int e = tid + GMPC_THREADS * j, r = e / BM, c = e % BM;
-      const bool ok = (k0 + r < K) && (m0 + c < a.M);
-      rx[j] = ok ? X[(size_t)(k0 + r) * ldx + m0 + c] : 0.f;
+      const int e = (tid + GMPC_THREADS * j) * VW, r = e / BM, c = e % BM;
+      const bool ok = (k0 + r < K) && (m0 + c < a.M);     // VEC: M % 4 == 0, so a group is in or out
+      rx[j] = ok ? *reinterpret_cast<const stage_t*>(X + (size_t)(k0 + r) * ldx + m0 + c) : zero();
     }
 #pragma unroll
     for (int j = 0; j < LY; ++j) {
-      const int e = tid + GMPC_THREADS * j, r = e / BN, c = e % BN;
+      const int e = (tid + GMPC_THREADS * j) * VW, r = e / BN, c = e % BN;
       const bool ok = (k0 + r < K) && (n0 + c < a.N);
-      ry[j] = ok ? Y[(size_t)(k0 + r) * ldy + n0 + c] : 0.f;
+      ry[j] = ok ? *reinterpret_cast<const stage_t*>(Y + (size_t)(k0 + r) * ldy + n0 + c) : zero();
     }
   };
   auto stage = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < LX; ++j) {
-      const int e = tid + GMPC_THREADS * j;
-      Xs[buf][e / BM][e % BM] = rx[j];
+      const int e = (tid + GMPC_THREADS * j) * VW;
+      *reinterpret_cast<stage_t*>(&Xs[buf][e / BM][e % BM]) = rx[j];
     }
 #pragma unroll
     for (int j = 0; j < LY; ++j) {
-      const int e = tid + GMPC_THREADS * j;
-      Ys[buf][e / BN][e % BN] = ry[j];
+      const int e = (tid + GMPC_THREADS * j) * VW;
+      *reinterpret_cast<stage_t*>(&Ys[buf][e / BN][e % BN]) = ry[j];
     }
   };
   issue(0);
@@ -210,7 +218,18 @@ static void launch_lds(const BgemmArgs& a, hipStream_t s) {
   constexpr int BM = 64 * WMT, BN = 64 * WNT;
   const long total = (long)a.batch * ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const long per = (total + 7) / 8;
-  hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT, GMPC_BG_KC>), dim3((unsigned)(per * 8)), dim3(GMPC_THREADS), 0, s, a);
+  auto al4 = [](const void* p_, long st, int ld) {
+    return p_ == nullptr || (((uintptr_t)p_ & 15) == 0 && (st & 3) == 0 && (ld & 3) == 0);
+  };
+  const bool vec = WNT != 3 && (a.M & 3) == 0 && (a.N & 3) == 0 && al4(a.X, a.sx, a.ldx) &&
+                   al4(a.Y, a.sy, a.ldy) && al4(a.K2 ? a.X2 : nullptr, a.sx2, a.ldx2) &&
+                   al4(a.K2 ? a.Y2 : nullptr, a.sy2, a.ldy2);
+  if (vec)
+    hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT == 3 ? 2 : WNT, GMPC_BG_KC, true>), dim3((unsigned)(per * 8)),
+                       dim3(GMPC_THREADS), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT, GMPC_BG_KC>), dim3((unsigned)(per * 8)), dim3(GMPC_THREADS), 0,
+                       s, a);
 }
 
 void gmpc_launch_bgemm_tn(const BgemmArgs& a, hipStream_t s) {
