@@ -17,7 +17,7 @@ def sliding_windows(traj, length, count, start=0):
         return np.empty((0, length) + traj.shape[1:], traj.dtype)
     view = np.lib.stride_tricks.sliding_window_view(traj, length, axis=0)   # [L-length+1, ..., length]
     view = np.moveaxis(view, -1, 1)                                          # [., length, ...]
-    return np.ascontiguousarray(view[start:start + count])
+    return np.array(view[start:start + count])          # always a writable copy
 
 
 class Buffer:
