@@ -59,6 +59,10 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
   for (int e = threadIdx.x; e < wl_floats; e += blockDim.x) wl_s[e] = lp.WLP[e];
   // tail rows 32 NT .. 32 NT + 7 of every hidden W_l^T: wt_s[l - 1][k][8]
   float* wt_s = wl_s + wl_floats;
+  // the padded W_1^T (2 KS x 32) of the input GEMM: one MFMA per k-step cannot hide an L2 round trip
+  // per operand, an LDS read it can
+  float* w1_s = wt_s + (TAIL > 0 ? (Lh - 1) * 2 * KS * 8 : 0);
+  for (int e = threadIdx.x; e < 2 * KS * 32; e += blockDim.x) w1_s[e] = lp.WTP[0][e];
   if (TAIL > 0) {
     for (int l = 1; l < Lh; ++l)
       for (int e = threadIdx.x; e < 2 * KS * 8; e += blockDim.x) {
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) acc0[rg] = 0.f;
     {
-      const float* __restrict__ ap = lp.WTP[0] + half * 32 + l31;
+      const float* ap = w1_s + half * 32 + l31;
       float a[6];
 #pragma unroll
       for (int j = 0; j < 5; ++j) a[j] = ap[j * 64];
@@ -242,6 +246,7 @@ static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const
   const int Lh = dyn.L - 1;
   size_t lds = (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n * sizeof(float);
   if (TAIL > 0) lds += (size_t)(Lh - 1) * 2 * KS * 8 * sizeof(float);
+  lds += (size_t)2 * KS * 32 * sizeof(float);
   if (lds > 64 * 1024) return -1;
   int grid = (ntiles + 3) / 4;
   if (grid > 256) grid = 256;   // one persistent workgroup per CU (one wave per SIMD: 512 registers)
