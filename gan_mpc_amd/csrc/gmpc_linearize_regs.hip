@@ -37,13 +37,16 @@ __device__ __forceinline__ void swap_halves(float& a, float& b) {
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 // TAIL = 8: the hidden width is 32 NT + 8 (200 = 6 x 32 + 8).  A seventh 32-row tile would be three
-// quarters padding; instead the last 8 rows go through v_mfma_f32_4x4x1_16B_f32, whose 16 blocks of
-// 4 x 4 are exactly 2 row groups x 8 column groups of this tile: one issue per k (8 cycles) instead
-// of a quarter-used 64-cycle issue per two k.  Its B operand wants the k row in BOTH lane halves (one
-// v_permlane32_swap of S[ks] with itself gives the rows 2 ks and 2 ks + 1 that way), its A operand
-// -- 8 weights per k -- comes from a small LDS table.
+// quarters padding; instead the last 8 rows go through v_mfma_f32_4x4x1_16B_f32.  Its 16 blocks of
+// 4 x 4 see S[ks] exactly as it lies in the registers: blocks 0..7 (lanes 0..31) hold k = 2 ks for the
+// columns 4 blk .. 4 blk + 3, blocks 8..15 the same columns for k = 2 ks + 1.  With the A operand
+// W[row r][k = 2 ks + half] the lower lane half accumulates the even-k partial sum and the upper half the
+// odd-k one; the halves are added once per layer in the epilogue.  Two issues per k-step (rows 0..3 and
+// 4..7, 8 cycles each), no operand shuffling in the loop (a v_permlane32_swap per k-step measured 32
+// cycles of a 490-cycle k-step), the A operands -- 8 weights per k -- come from a small LDS table.
 template <int NT, int KS, int TAIL = 0>
 __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
     int NSamp, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
@@ -114,28 +117,37 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
-      const float4* __restrict__ bp =
-          reinterpret_cast<const float4*>(lp.WTP[l]) + half * 64 + l31 * 2;
+      // weight operands through a buffer resource: the k-step offset is an SGPR / immediate, the lane
+      // offset one fixed VGPR -- no 64-bit VALU address arithmetic between the MFMAs (measured: the
+      // flat-address version spent 40 cycles of a 470-cycle k-step on its loads)
+      const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(lp.WTP[l]), 0, 2 * KS * 256 * (int)sizeof(float), 0x00020000);
+      const int woff = (half * 64 + l31 * 2) * 16;
+      auto wload = [&](int ks_, int j_) -> float4 {
+        const v4u r = __builtin_amdgcn_raw_buffer_load_b128(wrs, woff + 16 * j_, ks_ * 2048, 0);
+        return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z),
+                           __uint_as_float(r.w));
+      };
       constexpr int RD = GMPC_REGS_RING;      // operand ring: RD - 1 k-steps of weight loads in flight
       float4 w[RD][2];
 #pragma unroll
-      for (int j = 0; j < RD - 1; ++j) { w[j][0] = bp[j * 128]; w[j][1] = bp[j * 128 + 1]; }
+      for (int j = 0; j < RD - 1; ++j) { w[j][0] = wload(j, 0); w[j][1] = wload(j, 1); }
       // relu words of the layer this GEMM produces (loaded early, used in the epilogue)
       uint32_t mw[NT + 1];
 #pragma unroll
-      for (int t_ = 0; t_ < NT + (TAIL > 0 ? 1 : 0); ++t_) mw[t_] = mrow[(l - 1) * GMPC_MW + t_] >> (4 * half);
-      // two tail accumulators (even / odd k): back-to-back 4x4x1 issues into one accumulator would
-      // wait for each other; the A operands are read from LDS one k-step ahead
+      for (int t_ = 0; t_ < NT; ++t_) mw[t_] = mrow[(l - 1) * GMPC_MW + t_] >> (4 * half);
+      // two tail accumulators: rows 32 NT + {0..3} and 32 NT + {4..7}; the A operands are read from LDS
+      // one k-step ahead
       f32x4 acct = {0.f, 0.f, 0.f, 0.f}, acct2 = {0.f, 0.f, 0.f, 0.f};
-      const float* wtl = wt_s + (l - 1) * 2 * KS * 8 + 4 * half + (lane & 3);
-      float wte = TAIL > 0 ? wtl[0] : 0.f, wto = TAIL > 0 ? wtl[8] : 0.f;
-      float bte = S[0], bto = S[0];          // B operands of the tail, prepared one k-step ahead
-      if (TAIL > 0) swap_halves(bte, bto);   // bte: row 2 ks in both lane halves, bto: row 2 ks + 1
+      const float* wtl = wt_s + (l - 1) * 2 * KS * 8 + 8 * half + (lane & 3);
+      float wta = TAIL > 0 ? wtl[0] : 0.f, wtb = TAIL > 0 ? wtl[4] : 0.f;
+      uint32_t mwt = 0;
+      if (TAIL > 0) mwt = mrow[(l - 1) * GMPC_MW + NT] >> half;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         if (ks + RD - 1 < KS) {
-          w[(ks + RD - 1) % RD][0] = bp[(ks + RD - 1) * 128];
-          w[(ks + RD - 1) % RD][1] = bp[(ks + RD - 1) * 128 + 1];
+          w[(ks + RD - 1) % RD][0] = wload(ks + RD - 1, 0);
+          w[(ks + RD - 1) % RD][1] = wload(ks + RD - 1, 1);
         }
         const float b = S[ks];
         const float4 q0 = w[ks % RD][0], q1 = w[ks % RD][1];
@@ -148,17 +160,13 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
         if (NT > 6) acc[6 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.z, b, acc[6 % NT], 0, 0, 0);
         if (NT > 7) acc[7 % NT] = __builtin_amdgcn_mfma_f32_32x32x2f32(q1.w, b, acc[7 % NT], 0, 0, 0);
         if (TAIL > 0) {
-          const float be = bte, bo = bto;
-          const float ae = wte, ao = wto;
+          const float a03 = wta, a47 = wtb;
           if (ks + 1 < KS) {
-            wte = wtl[(2 * ks + 2) * 8];
-            wto = wtl[(2 * ks + 3) * 8];
-            bte = S[ks + 1 < KS ? ks + 1 : ks];
-            bto = bte;
-            swap_halves(bte, bto);
+            wta = wtl[(2 * ks + 2) * 8];
+            wtb = wtl[(2 * ks + 2) * 8 + 4];
           }
-          acct = __builtin_amdgcn_mfma_f32_4x4x1f32(ae, be, acct, 0, 0, 0);
-          acct2 = __builtin_amdgcn_mfma_f32_4x4x1f32(ao, bo, acct2, 0, 0, 0);
+          acct = __builtin_amdgcn_mfma_f32_4x4x1f32(a03, b, acct, 0, 0, 0);
+          acct2 = __builtin_amdgcn_mfma_f32_4x4x1f32(a47, b, acct2, 0, 0, 0);
         }
         // spread the two weight loads and their address arithmetic BETWEEN the MFMAs of the k-step:
         // issued as a block at the k-step boundary they do not overlap the matrix pipe (one wave per
@@ -192,13 +200,16 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_regs(
         }
       }
       if (TAIL > 0) {
-        // tail accumulator: lane half h holds rows 32 NT + 4 h + {0..3} of its column
-        acct += acct2;
-        float c0 = ((mw[NT] >> 0) & 1u) ? acct[0] : 0.f, c1 = ((mw[NT] >> 1) & 1u) ? acct[1] : 0.f;
-        float c2 = ((mw[NT] >> 2) & 1u) ? acct[2] : 0.f, c3 = ((mw[NT] >> 3) & 1u) ? acct[3] : 0.f;
-        swap_halves(c0, c1);      // c0: rows (+0, +1); c1: rows (+4, +5)
-        swap_halves(c2, c3);      // c2: rows (+2, +3); c3: rows (+6, +7)
-        S[16 * NT + 0] = c0; S[16 * NT + 1] = c2; S[16 * NT + 2] = c1; S[16 * NT + 3] = c3;
+        // tail: register j of acct / acct2 is row 32 NT + j / 32 NT + 4 + j of this lane's column, summed
+        // over the k of this lane half's parity.  One swap per row pair adds the two parities and leaves
+        // row 2 q in the lower and row 2 q + 1 in the upper half -- the B operand layout of S
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = q < 2 ? acct[2 * q] : acct2[2 * q - 4];
+          float y = q < 2 ? acct[2 * q + 1] : acct2[2 * q - 3];
+          swap_halves(x, y);      // x: (row 2q even-k | row 2q+1 even-k), y: the odd-k partial sums
+          S[16 * NT + q] = ((mwt >> (2 * q)) & 1u) ? x + y : 0.f;
+        }
       }
       GMPC_STAMP(2)
     }
