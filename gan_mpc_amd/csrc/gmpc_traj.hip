@@ -10,6 +10,8 @@
 // cost/nn.py:23-29, trajax rollout / evaluate / ddp_rollout / line_search_ddp as called from
 // policy/optimizers.py:19,26-29,55.
 #include "gmpc_device.h"
+#include <cstdlib>
+#include <cstring>
 
 #define GMPC_TRAJ_THREADS_ 512   // workgroup size of k_traj (see GMPC_TRAJ_THREADS)
 
@@ -90,13 +92,105 @@ __device__ __forceinline__ void out_layer32(const float* W, int K, int n, const 
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-weight MFMA form of the dynamics network (k_traj<LS, H, NHL>, 256 threads).
+//
+// The general form above re-reads every 200 x 200 weight matrix from L2 at each of the T steps
+// (160 KB per layer per step at ~20 B/clk per CU: 8k cycles, the rollout's floor).  Here the 4 waves
+// of the workgroup -- one per SIMD, 512 registers each -- keep the hidden matrices in their registers
+// for the whole horizon and multiply with v_mfma_f32_4x4x1_16B_f32, the one MFMA shape that runs at
+// full rate with 4 columns: the 4 trajectories of the workgroup.
+//   lane = (g, p): neuron group g = lane >> 2 (16 blocks of the MFMA), p = lane & 3
+//   block g:    D[i][c] += W[k][neuron 64 wave + 4 g + i] * act[k][slot c]       (one k per issue)
+//   A operand:  the lane's weight W[k][64 wave + lane]            (register wr[k], loaded once)
+//   B operand:  act[k][slot p] from the LDS row of slot p          (float4 = 4 k per read)
+//   D:          register i of lane (g, p) = neuron 64 wave + 4 g + i of slot p -> bias, relu bit, relu,
+//               one float4 store into row p of the next layer's B operand
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#define GMPC_RW_THREADS 256
+#define GMPC_RW_HP 204    // LDS row stride (floats) of a hidden activation row: 200 + 4, = 12 mod 32
+#define GMPC_RW_ZP 36     // row stride of the layer-0 input rows (n + m <= 32), = 4 mod 32
+
+__device__ __forceinline__ void rw_swap_halves(float& a, float& b) {
+  typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+  const v2u_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x);
+  b = __uint_as_float(r.y);
+}
+
+// epilogue of a hidden layer: bias, relu bits -> mask words 2 wave, 2 wave + 1 of the 4 slots, relu,
+// row p of hout
+__device__ __forceinline__ void rw_hidden_epilogue(f32x4_t d, const float (&bias)[4], int H, float* hout,
+                                                   uint32_t* mbase, size_t mstride, unsigned wbits) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 2, p = lane & 3;
+  float v[4];
+  unsigned long long word = 0ull;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = d[i] + bias[i];
+    // ballot bit 4 g + c: neuron 4 g + i of slot c; slot p keeps every fourth bit, moved to bit 4 g + i
+    const unsigned long long bal = __ballot(v[i] > 0.f);
+    word |= ((bal >> p) & 0x1111111111111111ull) << i;
+  }
+  if (mbase != nullptr && lane < 4 && ((wbits >> lane) & 1u)) {
+    uint32_t* mp = mbase + (size_t)lane * mstride + 2 * wave;
+    mp[0] = (uint32_t)word;
+    mp[1] = (uint32_t)(word >> 32);
+  }
+  const int k = 64 * wave + 4 * g;
+  if (k < H)
+    *reinterpret_cast<float4*>(hout + p * GMPC_RW_HP + k) =
+        make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+}
+
+// one H x H hidden layer: row p of hin -> accumulator of this lane's block.  The first H - XK weight
+// rows come from registers, the last XK from the LDS copy wx ([XK / 4][256 threads] float4): two
+// full layers (400 registers) plus the loop's working set do not fit 512 registers -- the compiler
+// spilled ~60 weights to scratch and waited for each reload in front of its MFMA
+#define GMPC_RW_XK 64
+template <int H, int XK>
+__device__ __forceinline__ f32x4_t rw_layer(const float (&wr)[H], const float* hin, const float4* wx) {
+  static_assert(H % 8 == 0 && XK % 4 == 0, "H");
+  const int lane = threadIdx.x & 63;
+  const float4* brow = reinterpret_cast<const float4*>(hin + (lane & 3) * GMPC_RW_HP);
+  f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f}, d3 = {0.f, 0.f, 0.f, 0.f};
+  constexpr int QR = (H - XK) / 4;     // float4 steps with register weights
+  float4 b0 = brow[0], b1 = brow[1], b2 = brow[2];
+  float4 x0 = make_float4(0.f, 0.f, 0.f, 0.f), x1 = x0;
+  if (XK > 0) { x0 = wx[threadIdx.x]; if (XK > 4) x1 = wx[GMPC_RW_THREADS + threadIdx.x]; }
+#pragma unroll
+  for (int q = 0; q < H / 4; ++q) {
+    const float4 b = b0;
+    b0 = b1;
+    b1 = b2;
+    if (q + 3 < H / 4) b2 = brow[q + 3];
+    float4 w;
+    if (q < QR) {
+      w = make_float4(wr[4 * q + 0], wr[4 * q + 1], wr[4 * q + 2], wr[4 * q + 3]);
+    } else {
+      w = x0;
+      x0 = x1;
+      if (q - QR + 2 < XK / 4) x1 = wx[(q - QR + 2) * GMPC_RW_THREADS + threadIdx.x];
+    }
+    d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, b.x, d0, 0, 0, 0);
+    d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, b.y, d1, 0, 0, 0);
+    d2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, b.z, d2, 0, 0, 0);
+    d3 = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, b.w, d3, 0, 0, 0);
+  }
+  return (d0 + d1) + (d2 + d3);
+}
+
 #ifndef GMPC_TRAJ_MINW
 #define GMPC_TRAJ_MINW 4
 #endif
 #define GMPC_TRAJ_THREADS 512   // k_traj: 8 waves, the upper 4 take the second half of every K range
 
-template <bool LS>
-__global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(TrajArgs a) {
+// KH > 0 selects the register-weight MFMA form of the dynamics network (hidden width KH, NHL hidden
+// KH x KH layers, 256 threads; see rw_layer above); KH = 0 is the general VALU form (512 threads).
+template <bool LS, int KH = 0, int NHL = 0>
+__global__ __launch_bounds__(KH ? GMPC_RW_THREADS : GMPC_TRAJ_THREADS, KH ? 1 : GMPC_TRAJ_MINW) void k_traj(TrajArgs a) {
   // dynamic LDS: actA | actB (aw float4 each: max(n+m, widest layer)) | part (pw) | ksp (256) | xcur (n)
   extern __shared__ __attribute__((aligned(16))) char smem_traj[];
   float4* const actA = reinterpret_cast<float4*>(smem_traj);
@@ -157,6 +251,58 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
   const float* const WL = a.swl ? wl_s : a.dyn.W[Lh];
   const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]), w2 = sigmoidf_(a.mpc_w[2]);
 
+  // ---- register-weight form (KH > 0): LDS rows behind the staged weights, weights and biases in
+  // registers for the whole horizon
+  float* const zT = wl_s + a.swl;                        // [4][ZP]   layer-0 input rows (x ; u) per slot
+  float* const usf = zT + 4 * GMPC_RW_ZP;                // [32][4]   controls of the step, [j][slot]
+  float* const hA = usf + 4 * 32;                        // [4][HP]   hidden activation rows, ping
+  float* const hB = hA + 4 * GMPC_RW_HP;                 //           pong
+  float* const op = hB + 4 * GMPC_RW_HP;                 // [4][32][4] output-layer partials per wave
+  float4* const wx_s = reinterpret_cast<float4*>(op + 4 * 32 * 4);   // [XK / 4][256] last XK weight rows
+                                                                     // of the last hidden layer
+  const int rg = lane >> 2, rp = lane & 3;
+  const int nnA = 64 * wave + lane;                      // neuron of this lane's A operand
+  float wr[NHL > 0 ? NHL : 1][KH > 0 ? KH : 1];
+  float rbias[NHL + 1][4];
+  if constexpr (KH > 0) {
+#pragma unroll
+    for (int hl = 0; hl < NHL; ++hl) {
+      const float* Wl = a.dyn.W[hl + 1];
+      const int kreg = hl == NHL - 1 ? KH - GMPC_RW_XK : KH;
+#pragma unroll
+      for (int k = 0; k < kreg; ++k) wr[hl][k] = nnA < KH ? Wl[(size_t)k * KH + nnA] : 0.f;
+      if (hl == NHL - 1) {
+#pragma unroll 4
+        for (int q = 0; q < GMPC_RW_XK / 4; ++q) {
+          const float* wq = Wl + (size_t)(KH - GMPC_RW_XK + 4 * q) * KH + nnA;
+          wx_s[q * GMPC_RW_THREADS + tid] =
+              nnA < KH ? make_float4(wq[0], wq[KH], wq[2 * KH], wq[3 * KH]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l <= NHL; ++l)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ne = 64 * wave + 4 * rg + i;
+        rbias[l][i] = ne < KH ? a.dyn.b[l][ne] : 0.f;
+      }
+    for (int e = tid; e < 4 * GMPC_RW_ZP + 4 * 32; e += blockDim.x) zT[e] = 0.f;
+    __syncthreads();
+  }
+  // output-layer bias of the state coordinate thread tid reduces (tid < 4 n)
+  const float rbl = (KH > 0 && tid < 4 * n) ? a.dyn.b[Lh][tid >> 2] : 0.f;
+  const float* const xs_ = KH > 0 ? xf : aAf;            // x_t and u_t of the four slots, [i][slot]
+  const float* const us_ = KH > 0 ? usf : aAf + 4 * n;
+  auto put_u = [&](int c, int j, float u) {
+    if (KH > 0) {
+      usf[j * 4 + c] = u;
+      zT[c * GMPC_RW_ZP + n + j] = u;
+    } else {
+      aAf[(n + j) * 4 + c] = u;
+    }
+  };
+
   {
     // bit c set: slot c writes its outputs
     unsigned wbits = 0;
@@ -169,6 +315,10 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
       float4 v = make_float4(xs[BI(0) * st + i], xs[BI(1) * st + i], xs[BI(2) * st + i],
                              xs[BI(3) * st + i]);
       xcur[i] = v;
+      if (KH > 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) zT[c * GMPC_RW_ZP + i] = f4get(v, c);
+      }
       if (!LS) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -193,12 +343,13 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
       // previous step's cost evaluation; the barriers of that step ordered them)
       if (LS && t > 0 && (s_live[0] | s_live[1] | s_live[2] | s_live[3]) == 0) { aborted = true; break; }
       // ---- controls and layer-0 input
-      for (int i = tid; i < n; i += blockDim.x) actA[i] = xcur[i];
+      if (KH == 0)
+        for (int i = tid; i < n; i += blockDim.x) actA[i] = xcur[i];
       if (LS) {
         // u = U + alpha k + K (x - X_nominal): 16 lanes share one (slot, control) inner product, so
         // the n gain / state loads of a control are issued together instead of one after another
         const int l16 = tid & 15;
-        for (int p = tid >> 4; p < GMPC_TB * m; p += GMPC_TRAJ_THREADS >> 4) {
+        for (int p = tid >> 4; p < GMPC_TB * m; p += blockDim.x >> 4) {
           const int c = p / m, j = p - c * m;
           const int bc = BI(c);
           const size_t ub = ((size_t)bc * T + t) * m + j;
@@ -213,12 +364,12 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
           if (l16 == 0) {
             const float u = a.Uio[ub] + fmaf(s_alpha[c], a.kg[ub], du);
             if ((wbits >> c) & 1u) a.Uc[(CI(c) * T + t) * m + j] = u;
-            aAf[(n + j) * 4 + c] = u;
+            put_u(c, j, u);
           }
         }
       } else if (tid < GMPC_TB * m) {
         const int c = tid / m, j = tid % m;
-        aAf[(n + j) * 4 + c] = a.U[((size_t)BI(c) * T + t) * m + j];
+        put_u(c, j, a.U[((size_t)BI(c) * T + t) * m + j]);
       }
       __syncthreads();
       TS_(0)
@@ -232,17 +383,17 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
           const float gi = gnext;
           if (lane < n) {
             gnext = g[n + lane];           // row t + 1 (exists: the goal has T + 1 rows)
-            const float d = aAf[lane * 4 + c] - gi;
+            const float d = xs_[lane * 4 + c] - gi;
             dd = d * d;
           }
         } else {
           for (int i = lane; i < n; i += 64) {
-            const float d = aAf[i * 4 + c] - g[i];
+            const float d = xs_[i * 4 + c] - g[i];
             dd = fmaf(d, d, dd);
           }
         }
         for (int j = lane; j < m; j += 64) {
-          const float u = aAf[(n + j) * 4 + c];
+          const float u = us_[j * 4 + c];
           uu = fmaf(u, u, uu);
         }
         dd = wave_sum(dd);
@@ -254,6 +405,83 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
         if (!LS && lane == 0 && INB(c) && a.costs) a.costs[(size_t)bc * (T + 1) + t] = cst;
       }
       TS_(1)
+      if constexpr (KH > 0) {
+        // ---- the dynamics network on the matrix pipe (see rw_layer)
+        uint32_t* mb = (LS ? a.maskc : a.masks) + (size_t)b0 * mstride + (size_t)t * Lh * GMPC_MW;
+        {
+          // layer 0: A operand from the LDS copy of W_0 ([k][H]); rows k >= n + m of zT are zero
+          const int K0 = n + m;
+          const float4* brow = reinterpret_cast<const float4*>(zT + rp * GMPC_RW_ZP);
+          const float* wcol = W0 + (nnA < KH ? nnA : 0);
+          f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+          for (int q = 0; 4 * q < K0; ++q) {
+            const float4 b = brow[q];
+            float aw[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int k = 4 * q + e;
+              aw[e] = (k < K0 && nnA < KH) ? wcol[(size_t)k * KH] : 0.f;
+            }
+            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[0], b.x, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[1], b.y, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[2], b.z, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(aw[3], b.w, d1, 0, 0, 0);
+          }
+          rw_hidden_epilogue(d0 + d1, rbias[0], KH, hA, mb, mstride, wbits);
+        }
+        __syncthreads();
+        TS_(2)
+        float* hin = hA;
+        float* hout = hB;
+#pragma unroll
+        for (int hl = 0; hl < NHL; ++hl) {
+          const f32x4_t d = hl == NHL - 1 ? rw_layer<KH, GMPC_RW_XK>(wr[hl], hin, wx_s)
+                                          : rw_layer<KH, 0>(wr[hl], hin, wx_s);
+          rw_hidden_epilogue(d, rbias[hl + 1], KH, hout, mb + (hl + 1) * GMPC_MW, mstride, wbits);
+          __syncthreads();
+          TS_(3 + hl)
+          float* tmp = hin; hin = hout; hout = tmp;
+        }
+        {
+          // output layer: the K range is split over the 4 waves and the two lane halves; block
+          // (ph, og) of the MFMA: outputs 4 og + i, k = KW wave + 2 e + ph
+          constexpr int KW = KH / 4;
+          const int ph = lane >> 5, og = rg & 7;
+          const int no = 4 * og + rp;
+          const float* brow = hin + rp * GMPC_RW_HP + KW * wave + ph;
+          const float* wcol = WL + (size_t)(KW * wave + ph) * n + (no < n ? no : 0);
+          f32x4_t d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < (KW + 1) / 2; ++e) {
+            const bool kin = 2 * e + ph < KW;
+            const float aw = (no < n && kin) ? wcol[(size_t)2 * e * n] : 0.f;
+            const float bv = kin ? brow[2 * e] : 0.f;
+            d = __builtin_amdgcn_mfma_f32_4x4x1f32(aw, bv, d, 0, 0, 0);
+          }
+          float a0 = d[0], a1 = d[1], a2 = d[2], a3 = d[3];
+          rw_swap_halves(a0, a1);      // a0 + a1: output 4 og + ph, both k phases
+          rw_swap_halves(a2, a3);      // a2 + a3: output 4 og + 2 + ph
+          op[(wave * 32 + 4 * og + ph) * 4 + rp] = a0 + a1;
+          op[(wave * 32 + 4 * og + 2 + ph) * 4 + rp] = a2 + a3;
+        }
+        __syncthreads();
+        if (tid < 4 * n) {
+          const int no = tid >> 2, c = tid & 3;
+          float sum = op[no * 4 + c];
+#pragma unroll
+          for (int w = 1; w < GMPC_RW_THREADS / 64; ++w) sum += op[(w * 32 + no) * 4 + c];
+          const float v = (sum + rbl) + xf[no * 4 + c];
+          xf[no * 4 + c] = v;
+          zT[c * GMPC_RW_ZP + no] = v;
+          if ((wbits >> c) & 1u) {
+            float* Xo = LS ? a.Xc : a.X;
+            Xo[((LS ? CI(c) : (size_t)BI(c)) * (T + 1) + t + 1) * n + no] = v;
+          }
+        }
+        __syncthreads();
+        TS_(6)
+        continue;
+      }
       // ---- hidden layers
       float4* in = actA;
       float4* out = actB;
@@ -312,7 +540,7 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
       const int Lc = a.cost.L - 1;
       for (int l = 0; l < Lc; ++l) {
         hidden_layer(a.cost.W[l], a.cost.b[l], a.cost.dims[l], a.cost.dims[l + 1], in, out, nullptr, 0,
-                     0u, ksp);
+                     0u, KH > 0 ? nullptr : ksp);
         __syncthreads();
         in = out;
         out = (out == actA) ? actB : actA;
@@ -534,8 +762,27 @@ static int traj_aw(int n, int m, const MlpDesc& d1, const MlpDesc* d2) {
   if (d2) for (int l = 0; l <= d2->L; ++l) w = d2->dims[l] > w ? d2->dims[l] : w;
   return (w + 3) & ~3;
 }
-static size_t traj_lds(TrajArgs& a) {
+// register-weight form: three equal hidden layers of width 200, state and control within one MFMA block row
+static bool traj_rw_shape(const TrajArgs& a) {
+  static const bool off = getenv("GMPC_TRAJ") != nullptr && strcmp(getenv("GMPC_TRAJ"), "valu") == 0;
+  const int Lh = a.dyn.L - 1;
+  if (off || Lh != 3 || a.n > 32 || a.m > 32 || a.n + a.m > 32) return false;
+  for (int l = 1; l <= Lh; ++l)
+    if (a.dyn.dims[l] != 200) return false;
+  return true;
+}
+static size_t traj_lds(TrajArgs& a, bool rw = false) {
   a.aw = traj_aw(a.n, a.m, a.dyn, &a.cost);
+  if (rw) {
+    // one workgroup per CU (the registers hold the weights): both small matrices and the rows of the
+    // MFMA form go to LDS without the 64 KB consideration below
+    a.pw = GMPC_RW_THREADS;
+    a.sw0 = a.dyn.dims[0] * a.dyn.dims[1];
+    a.swl = a.dyn.dims[a.dyn.L - 1] * a.n;
+    return ((size_t)2 * a.aw + a.pw + GMPC_THREADS + a.n) * sizeof(float4) +
+           ((size_t)a.sw0 + a.swl + 4 * GMPC_RW_ZP + 4 * 32 + 2 * 4 * GMPC_RW_HP + 4 * 32 * 4 +
+            (size_t)GMPC_RW_XK * GMPC_RW_THREADS) * sizeof(float);
+  }
   a.pw = a.n > GMPC_TRAJ_THREADS ? a.n : GMPC_TRAJ_THREADS;
   size_t bytes = ((size_t)2 * a.aw + a.pw + GMPC_THREADS + a.n) * sizeof(float4);
   // W_0 and W_L in LDS while the workgroup stays under 64 KB (two workgroups per CU in the line search)
@@ -557,17 +804,22 @@ static void traj_attr(KernelT k) {
 
 void gmpc_launch_rollout(const TrajArgs& a0, hipStream_t s) {
   TrajArgs a = a0;
-  const size_t lds = traj_lds(a);
+  const bool rw = traj_rw_shape(a);
+  const size_t lds = traj_lds(a, rw);
   static bool attr = false;
-  if (!attr) { traj_attr(&k_traj<false>); attr = true; }
+  if (!attr) { traj_attr(&k_traj<false>); traj_attr(&k_traj<false, 200, 2>); attr = true; }
   const int grid = (a.B + GMPC_TB - 1) / GMPC_TB;
-  hipLaunchKernelGGL(k_traj<false>, dim3(grid), dim3(GMPC_TRAJ_THREADS), lds, s, a);
+  if (rw)
+    hipLaunchKernelGGL((k_traj<false, 200, 2>), dim3(grid), dim3(GMPC_RW_THREADS), lds, s, a);
+  else
+    hipLaunchKernelGGL(k_traj<false>, dim3(grid), dim3(GMPC_TRAJ_THREADS), lds, s, a);
 }
 int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s) {
   TrajArgs a = a0;
-  const size_t lds = traj_lds(a);
+  const bool rw = traj_rw_shape(a);
+  const size_t lds = traj_lds(a, rw);
   static bool attr = false;
-  if (!attr) { traj_attr(&k_traj<true>); attr = true; }
+  if (!attr) { traj_attr(&k_traj<true>); traj_attr(&k_traj<true, 200, 2>); attr = true; }
   // halvings allowed by trajax' loop: candidate k runs while alpha_0 / 2^k > alpha_min
   int k_max = 0;
   for (float al = a.alpha_0; al > a.alpha_min && k_max < 4096; al *= 0.5f) ++k_max;
@@ -582,8 +834,11 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s) {
                        w.slot, w.counts + r);
     a.item_b = w.item_b[0]; a.item_k = w.item_k[0]; a.nitems = w.counts + r; a.objc = w.objc;
     const long max_items = (long)a.B * (r == 0 ? GMPC_LS_ITEMS : GMPC_LS_NEXT);
-    hipLaunchKernelGGL(k_traj<true>, dim3((unsigned)((max_items + GMPC_TB - 1) / GMPC_TB)),
-                       dim3(GMPC_TRAJ_THREADS), lds, s, a);
+    const dim3 lsgrid((unsigned)((max_items + GMPC_TB - 1) / GMPC_TB));
+    if (rw)
+      hipLaunchKernelGGL((k_traj<true, 200, 2>), lsgrid, dim3(GMPC_RW_THREADS), lds, s, a);
+    else
+      hipLaunchKernelGGL(k_traj<true>, lsgrid, dim3(GMPC_TRAJ_THREADS), lds, s, a);
     LsDecideArgs d;
     d.n = a.n; d.m = a.m; d.T = a.T; d.Lh = a.dyn.L - 1; d.k_max = k_max;
     d.alpha_0 = a.alpha_0;
