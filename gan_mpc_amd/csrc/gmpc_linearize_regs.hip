@@ -25,9 +25,10 @@
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
 #define GMPC_LIN_PADROWS 24
-#ifndef GMPC_REGS_OCC
-#define GMPC_REGS_OCC 1
-#endif
+// waves per SIMD: the 200-wide instantiation fits 256 registers, and with two waves per SIMD the
+// seeds, epilogues and stores of one wave overlap the other's MFMAs (lqr_backward 1.539 -> 1.507 ms);
+// the other shapes keep one wave and its 512 registers
+#define GMPC_REGS_OCC(NT, TAIL) (((NT) == 6 && (TAIL) == 8) ? 2 : 1)
 #ifndef GMPC_REGS_RING
 #define GMPC_REGS_RING 3
 #endif
@@ -51,7 +52,7 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // 4..7, 8 cycles each), no operand shuffling in the loop (a v_permlane32_swap per k-step measured 32
 // cycles of a 490-cycle k-step), the A operands -- 8 weights per k -- come from a small LDS table.
 template <int NT, int KS, int TAIL = 0>
-__global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC) void k_linearize_regs(
+__global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linearize_regs(
     int NSamp, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
     float* AB, int ntiles, int samp_mul, int samp_add) {
   static_assert(NT <= 8 && 2 * KS <= 32 * NT + TAIL && (TAIL == 0 || TAIL == 8), "shape");
@@ -263,7 +264,8 @@ static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const
   lds += (size_t)2 * KS * 32 * sizeof(float);
   if (lds > 64 * 1024) return -1;
   int grid = (ntiles + 3) / 4;
-  if (grid > 256 * GMPC_REGS_OCC) grid = 256 * GMPC_REGS_OCC;   // persistent workgroups, GMPC_REGS_OCC per CU
+  constexpr int occ = GMPC_REGS_OCC(NT, TAIL);
+  if (grid > 256 * occ) grid = 256 * occ;   // persistent workgroups, occ per CU
   hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
                      dyn, lp, masks, active, AB, ntiles, samp_mul, samp_add);
   return 0;
