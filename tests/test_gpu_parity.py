@@ -19,6 +19,11 @@ SHAPES = {
     "c1-pendulum": (3, 1, 20, 32, {}),
     "c2-cheetah": (17, 6, 50, 48, {}),
     "trained-like": (17, 6, 50, 32, dict(out_scale=0.1)),
+    # the register-weight MFMA rollout (three hidden layers of 200) off its headline shape: n + m = 31 (the
+    # 8-group layer-0 instantiation), 4 m > 32 (controls without the one-step-ahead operands), T > 64 (two
+    # chunks of the after-the-horizon cost pass), batch not a multiple of the 4 slots of a workgroup
+    "rw-wide-io": (22, 9, 70, 6, dict(out_scale=0.3)),
+    "rw-ragged": (17, 6, 9, 7, {}),
     "wide": (40, 9, 6, 5, dict(dyn_hidden=(256, 64), cost_hidden=(256, 100), cost_fout=32)),
     # equal-width hidden layers of 128 / 64: the other instantiations of the register-resident chain
     "regs-128": (9, 3, 7, 11, dict(dyn_hidden=(128, 128), cost_hidden=(32,), cost_fout=4)),
@@ -160,7 +165,7 @@ def test_adam_clip_step():
         gu.assert_parity(f"adam v step {step}", vd.cpu().numpy(), v, v64)
 
 
-@pytest.mark.parametrize("name", ["tiny-ragged", "trained-like", "big-70"])
+@pytest.mark.parametrize("name", ["tiny-ragged", "trained-like", "big-70", "rw-wide-io", "rw-ragged"])
 def test_ilqr_single_iteration_teacher_forced(name):
     """maxiter=1 from the same start: tvlqr + line search + re-linearisation, one iteration."""
     pb, pb64, eng = _setup(name)
