@@ -213,6 +213,9 @@ __device__ __forceinline__ f32x4_t rw_out_part(const float4* hin, const float* w
 #pragma unroll
   for (int q = 0; q < (K1 - K0) / 4; ++q) wv[q] = wrow[q];
   f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+  // all operand reads go out before the first MFMA (left to itself hipcc issues one read per 4 MFMAs and
+  // waits for each: 13 LDS round trips, 1.3 k cycles of the step)
+  __builtin_amdgcn_sched_barrier(0);
   rw_static_for<(K1 - K0) / 4>([&](auto qc) __attribute__((always_inline)) {
     constexpr int q = decltype(qc)::value;
     constexpr int k = K0 + 4 * q;
