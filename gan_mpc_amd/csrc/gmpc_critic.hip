@@ -45,11 +45,24 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd
 #pragma unroll
     for (int k = 0; k < KC; ++k) wreg[k] = tid < G4 ? cd.Wcat[(size_t)k * G4 + tid] : 0.f;
   }
+  // x_t of the next step is requested one step ahead when one element per thread covers it
+  const bool xpf = n * SB <= (int)blockDim.x;
+  const int xsb = tid / (n > 0 ? n : 1), xi = tid - xsb * n;
+  const bool xon = xpf && tid < n * SB;
+  const float* xptr = xseq + ((size_t)min(s0 + (xon ? xsb : 0), Bc - 1) * T1) * n + (xon ? xi : 0);
+  float xnext = xon ? xptr[0] : 0.f;
   for (int t = 0; t < T1; ++t) {
-    for (int e = tid; e < n * SB; e += blockDim.x) {
-      const int sb = e / n, i = e - sb * n;
-      const int s = min(s0 + sb, Bc - 1);
-      actf[i * SB + sb] = xseq[((size_t)s * T1 + t) * n + i];
+    if (xpf) {
+      if (xon) {
+        actf[xi * SB + xsb] = xnext;
+        if (t + 1 < T1) xnext = xptr[(size_t)(t + 1) * n];
+      }
+    } else {
+      for (int e = tid; e < n * SB; e += blockDim.x) {
+        const int sb = e / n, i = e - sb * n;
+        const int s = min(s0 + sb, Bc - 1);
+        actf[i * SB + sb] = xseq[((size_t)s * T1 + t) * n + i];
+      }
     }
     __syncthreads();
     // save h_{t-1}
@@ -73,7 +86,24 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd
         acc[q] = make_float4(bj + v[0], bj + v[1], bj + v[2], bj + v[3]);
       }
     }
-    if (NXR > 0) {
+    if (NXR > 0 && R4 == 1) {
+      // 4 sequences: the [x ; h] image IS the broadcast A operand of v_mfma_f32_4x4x1 (gmpc_device.h),
+      // this thread's weight column the B operand -- 6 LDS reads and 81 MFMAs per step instead of 81
+      // broadcast ds_read_b128 and 324 FMAs per thread
+      constexpr int NR = (4 * KC + 63) / 64;
+      const int ln = tid & 63;
+      float ar[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) ar[r] = actf[64 * r + ln];
+      f32x4_t d0 = {bj, bj, bj, bj}, d1 = {0.f, 0.f, 0.f, 0.f};
+      rw_static_for<KC>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k & 1) rw_mfma<k>(d1, ar[k >> 4], wreg[k]);
+        else rw_mfma<k>(d0, ar[k >> 4], wreg[k]);
+      });
+      const f32x4_t d = d0 + d1;
+      acc[0] = make_float4(d[0], d[1], d[2], d[3]);
+    } else if (NXR > 0) {
 #pragma unroll
       for (int k = 0; k < KC; ++k)
 #pragma unroll
@@ -264,7 +294,14 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd
   if (stage_w)
     for (int e = tid; e < K * G4; e += blockDim.x) wlds[e] = cd.WcatT[e];
   const int jr = NXR > 0 ? tid % KC : 0, segr = NXR > 0 ? tid / KC : 0;
-  if (NXR > 0) {
+  // MFMA form (R4 == 1): this lane's 128 transposed weights WcatT[128 (wave >> 1) + j][64 (wave & 1) + lane]
+  float wtm[(NXR > 0 && R4 == 1) ? 128 : 1];
+  if (NXR > 0 && R4 == 1) {
+    const int k = ((tid >> 6) & 1) * 64 + (tid & 63);
+#pragma unroll
+    for (int j = 0; j < 128; ++j)
+      wtm[j] = k < KC ? cd.WcatT[(size_t)(((tid >> 6) >> 1) * 128 + j) * KC + k] : 0.f;
+  } else if (NXR > 0) {
 #pragma unroll
     for (int kk = 0; kk < KSG; ++kk) {
       const int k = segr * KSG + kk;
@@ -308,7 +345,33 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd
     }
     __syncthreads();
     // [dx ; dh_prev][k][sb] = sum_j WcatT[j][k] dz[j][sb]
-    if (NXR > 0) {
+    if (NXR > 0 && R4 == 1) {
+      // 4 sequences: dz IS the broadcast A operand ([j][4 slots]), the transposed weights the B operand:
+      // output column k = 64 (wave & 1) + lane, the 256 gate rows split over the wave pairs
+      constexpr int JH = 128;                       // gate rows per wave pair
+      const int ln = tid & 63, wv = tid >> 6;
+      const float* dzh = dzf + (wv >> 1) * JH * 4;
+      float ar[JH / 16];
+#pragma unroll
+      for (int r = 0; r < JH / 16; ++r) ar[r] = dzh[64 * r + ln];
+      f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      rw_static_for<JH>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j & 1) rw_mfma<j>(d1, ar[j >> 4], wtm[j]);
+        else rw_mfma<j>(d0, ar[j >> 4], wtm[j]);
+      });
+      const f32x4_t d = d0 + d1;
+      const int k = (wv & 1) * 64 + ln;
+      if (k < KC) part[(wv >> 1) * KC + k] = make_float4(d[0], d[1], d[2], d[3]);
+      __syncthreads();
+      for (int e = tid; e < KC; e += blockDim.x) {
+        float4 sm = part[e];
+        const float4 pp = part[KC + e];
+        sm.x += pp.x; sm.y += pp.y; sm.z += pp.z; sm.w += pp.w;
+        part[e] = sm;
+      }
+      __syncthreads();
+    } else if (NXR > 0) {
       if (segr < NSEG) {
         float4 acc[R4];
 #pragma unroll

@@ -1,6 +1,7 @@
 // Device-side building blocks shared by the gfx950 kernels of libgan_mpc_amd.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <utility>
 #include <stdint.h>
 #include <type_traits>
 
@@ -434,4 +435,27 @@ __device__ __forceinline__ void gemm_tile_1(int Kp, AL aload, AFIN afin, BF bfn,
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// v_mfma_f32_4x4x1_16B_f32 with a broadcast A operand (used by the register-weight trajectory kernels
+// and the LSTM kernels): B = one weight per lane (64 output columns per wave), A = act[k][slot] for
+// 4 "slots", broadcast to all 16 blocks with cbsz = 4 / abid = k & 15 -- one VGPR holds 16 consecutive
+// k of a [k][4 slots] float array read as 64 consecutive floats.  D register i of a lane = its column
+// for slot i.  Exact fp32 FMAs at 8 cycles per k and wave.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// compile-time loop: abid is an immediate of the MFMA, so k has to be a constant expression
+template <int... Is, typename F>
+__device__ __forceinline__ void rw_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void rw_static_for(F&& f) {
+  rw_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+// d += act[k][.] (x) w for one k: ar holds rows 16 r .. 16 r + 15 of the activations
+template <int K>
+__device__ __forceinline__ void rw_mfma(f32x4_t& d, float ar, float w) {
+  d = __builtin_amdgcn_mfma_f32_4x4x1f32(ar, w, d, 4, K & 15, 0);
 }

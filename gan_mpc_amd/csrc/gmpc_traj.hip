@@ -110,25 +110,10 @@ __device__ __forceinline__ void out_layer32(const float* W, int K, int n, const 
 //   D:          register i of a lane = its neuron for slot i -> relu ballot i IS the mask word pair of
 //               slot i; bias, relu and one float4 store give the next layer's activations
 // ------------------------------------------------------------------------------------------------
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
 #define GMPC_RW_THREADS 256
 #define GMPC_RW_XK 64     // weight rows of the last hidden layer kept in LDS instead of registers
 #define GMPC_RW_KHP 204   // row stride of the transposed W_L copy ([n][KHP], KHP = H + 4)
 
-// compile-time loop: abid is an immediate of the MFMA, so k has to be a constant expression
-template <int... Is, typename F>
-__device__ __forceinline__ void rw_static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void rw_static_for(F&& f) {
-  rw_static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-// d += act[k][.] (x) w for one k: ar holds rows 16 r .. 16 r + 15 of the activations
-template <int K>
-__device__ __forceinline__ void rw_mfma(f32x4_t& d, float ar, float w) {
-  d = __builtin_amdgcn_mfma_f32_4x4x1f32(ar, w, d, 4, K & 15, 0);
-}
 // weight rows of a layer that live in LDS: 8 q + {2, 3, 6, 7} for q < QX
 __host__ __device__ constexpr bool rw_row_in_lds(int k, int QX) { return (k >> 3) < QX && (k & 2) != 0; }
 // register index of weight row k (rows in LDS are skipped)
