@@ -317,16 +317,41 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd
     dh[e] = dhT[(size_t)s * F + u];
     dc[e] = 0.f;
   }
+  // the saved gates and cell states of step t - 1 are requested while step t is processed: the sweep
+  // never waits for a global round trip (the cell state of t - 1 is also step t's c_prev)
+  float pg[SPT][4], pc[SPT];
+  auto pf_load = [&](int t) {
+#pragma unroll
+    for (int e = 0; e < SPT; ++e) {
+      const int s = min(s0 + grp * SPT + e, Bc - 1);
+      const size_t gb = ((size_t)s * T1 + t) * G4;
+      pg[e][0] = gates[gb + u]; pg[e][1] = gates[gb + F + u];
+      pg[e][2] = gates[gb + 2 * F + u]; pg[e][3] = gates[gb + 3 * F + u];
+      pc[e] = t > 0 ? cs[((size_t)s * T1 + t - 1) * F + u] : 0.f;
+    }
+  };
+  float ccur[SPT];
+#pragma unroll
+  for (int e = 0; e < SPT; ++e)
+    ccur[e] = cs[((size_t)min(s0 + grp * SPT + e, Bc - 1) * T1 + T1 - 1) * F + u];
+  pf_load(T1 - 1);
   for (int t = T1 - 1; t >= 0; --t) {
+    float gq[SPT][4], cq[SPT];
+#pragma unroll
+    for (int e = 0; e < SPT; ++e) {
+      gq[e][0] = pg[e][0]; gq[e][1] = pg[e][1]; gq[e][2] = pg[e][2]; gq[e][3] = pg[e][3];
+      cq[e] = pc[e];
+    }
+    if (t > 0) pf_load(t - 1);
 #pragma unroll
     for (int e = 0; e < SPT; ++e) {
       const int sb = grp * SPT + e;
       const int s = min(s0 + sb, Bc - 1);
       const size_t gb = ((size_t)s * T1 + t) * G4;
-      const float ig = gates[gb + u], fg = gates[gb + F + u], gg = gates[gb + 2 * F + u],
-                  og = gates[gb + 3 * F + u];
-      const float ct = cs[((size_t)s * T1 + t) * F + u];
-      const float cprev = t > 0 ? cs[((size_t)s * T1 + t - 1) * F + u] : 0.f;
+      const float ig = gq[e][0], fg = gq[e][1], gg = gq[e][2], og = gq[e][3];
+      const float ct = ccur[e];
+      const float cprev = cq[e];
+      ccur[e] = cprev;
       const float tc = tanhf(ct);
       const float d_o = dh[e] * tc;
       dc[e] = dc[e] + dh[e] * og * (1.f - tc * tc);
