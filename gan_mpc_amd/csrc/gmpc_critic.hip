@@ -9,6 +9,7 @@
 // the concatenated kernel Wcat = [Wx; Wh] ((n+F) x 4F, exactly the flat critic layout), the cell
 // update runs as thread (unit, wave).  Saved per (sequence, step): activated gates, c_t, h_{t-1}.
 #include "gmpc_device.h"
+#include <cstdlib>
 
 
 // NXR > 0: the input size n is known at compile time and thread j keeps column j of [Wx; Wh]
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd
         acc[q] = make_float4(bj + v[0], bj + v[1], bj + v[2], bj + v[3]);
       }
     }
-    if (NXR > 0 && R4 == 1) {
+    if constexpr (NXR > 0 && R4 == 1) {
       // 4 sequences: the [x ; h] image IS the broadcast A operand of v_mfma_f32_4x4x1 (gmpc_device.h),
       // this thread's weight column the B operand -- 6 LDS reads and 81 MFMAs per step instead of 81
       // broadcast ds_read_b128 and 324 FMAs per thread
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd
       });
       const f32x4_t d = d0 + d1;
       acc[0] = make_float4(d[0], d[1], d[2], d[3]);
-    } else if (NXR > 0) {
+    } else if constexpr (NXR > 0) {
 #pragma unroll
       for (int k = 0; k < KC; ++k)
 #pragma unroll
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd
     }
     __syncthreads();
     // [dx ; dh_prev][k][sb] = sum_j WcatT[j][k] dz[j][sb]
-    if (NXR > 0 && R4 == 1) {
+    if constexpr (NXR > 0 && R4 == 1) {
       // 4 sequences: dz IS the broadcast A operand ([j][4 slots]), the transposed weights the B operand:
       // output column k = 64 (wave & 1) + lane, the 256 gate rows split over the wave pairs
       constexpr int JH = 128;                       // gate rows per wave pair
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd
         part[e] = sm;
       }
       __syncthreads();
-    } else if (NXR > 0) {
+    } else if constexpr (NXR > 0) {
       if (segr < NSEG) {
         float4 acc[R4];
 #pragma unroll
@@ -816,7 +817,63 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_colsum(int cs_rows, int N, con
 // (the trailing workgroups), and ONE launch reduces all the partial sums, in the same fixed chunk
 // order as before (deterministic).  Problems need N % 256 == 0.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GMPC_THREADS) void k_wgrad_batch(WgBatch bt, float* part) {
+// C(32 x 256) += A^T B over Kp rows for one wave: row r of A / B is the MFMA A / B operand of k-step r / 2.
+// B goes through 16-byte loads: lane l31 holds columns 4 l31 .. 4 l31 + 3 of each 128-column half, so tile j
+// of the accumulator is columns 128 (j >> 2) + 4 l31 + (j & 3) (the store undoes the permutation); the
+// operands of D k-steps are in flight.  Measured (LSTM + head problems of the headline step, batch kernel +
+// reductions): 8 tiles / ring 3 / dword loads 0.227 ms; 8 tiles, ring 8 or 12, one wave per SIMD 0.232;
+// 8 tiles, ring 4, two waves 0.183; 4 tiles, ring 4, four waves 0.172 -- the rows stream from HBM and it
+// is occupancy, not ring depth, that hides their latency.
+template <int D, int NTW, typename AF>
+__device__ __forceinline__ void wgrad_tile_x4(const float* __restrict__ bp0, int ldb, int Kp, AF afn,
+                                              f32x16 (&acc)[NTW]) {
+  static_assert(NTW == 4 || NTW == 8, "one or two 16-byte loads per lane and k-step");
+  float4 b[D][NTW / 4];
+  float a[D];
+  const int nks = Kp >> 1;
+  auto load = [&](int slot, int ks) {
+    const float4* bp = reinterpret_cast<const float4*>(bp0 + (size_t)2 * ks * ldb);
+    b[slot][0] = bp[0];
+    if (NTW > 4) b[slot][NTW / 4 - 1] = bp[32];
+    a[slot] = afn(2 * ks);
+  };
+#pragma unroll
+  for (int j = 0; j < D - 1; ++j)
+    if (j < nks) load(j, j);
+  for (int k0 = 0; k0 < nks; k0 += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int ks = k0 + u;
+      if (ks + D - 1 < nks) load((u + D - 1) % D, ks + D - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks < nks) {
+        const float av = a[u];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][0].x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][0].y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][0].z, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][0].w, acc[3], 0, 0, 0);
+        if (NTW > 4) {
+          acc[NTW - 4] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][NTW / 4 - 1].x, acc[NTW - 4], 0, 0, 0);
+          acc[NTW - 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][NTW / 4 - 1].y, acc[NTW - 3], 0, 0, 0);
+          acc[NTW - 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][NTW / 4 - 1].z, acc[NTW - 2], 0, 0, 0);
+          acc[NTW - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][NTW / 4 - 1].w, acc[NTW - 1], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+#ifndef GMPC_WG_RING
+#define GMPC_WG_RING 4     // k-steps of operands in flight per wave
+#endif
+#ifndef GMPC_WG_OCC
+#define GMPC_WG_OCC 4      // waves per SIMD: the rows stream from HBM, occupancy hides what the ring does not
+#endif
+#ifndef GMPC_WG_NTW
+#define GMPC_WG_NTW 4      // 32-column tiles per wave item (64 accumulator registers)
+#endif
+__global__ __launch_bounds__(GMPC_THREADS, GMPC_WG_OCC) void k_wgrad_batch(WgBatch bt, float* part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x >= bt.gemm_blocks) {
     // bias column sums: one workgroup per (problem, row chunk)
@@ -841,7 +898,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_wgrad_batch(WgBatch bt, float*
     }
     return;
   }
-  constexpr int NTW = 8;
+  constexpr int NTW = GMPC_WG_NTW;
   const int item = blockIdx.x * (GMPC_THREADS / 64) + wave;
   int pi = 0;
   for (int i = 1; i < bt.np; ++i)
@@ -871,12 +928,22 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_wgrad_batch(WgBatch bt, float*
   for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) acc[nt][rg] = 0.f;
-  const float* bp0 = q.B + (size_t)(r0 + half) * q.ldb + ng * 32 * NTW + l31;
-  gemm_tile<NTW>(bp0, q.ldb, Kp, afn, acc);
+  // (rows past the chunk meet a zero A operand; the B reads stay inside the array: the last chunk's
+  // odd tail row is clamped by the row pointer below)
+  const float* bp0 = q.B + (size_t)(r0 + half) * q.ldb + ng * 32 * NTW + 4 * l31;
+  if (r0 + Kp > rows) {      // wave-uniform
+    // the chunk's last k-step would read row `rows`: run it from a clamped pointer
+    wgrad_tile_x4<GMPC_WG_RING, NTW>(bp0, q.ldb, Kp - 2, afn, acc);
+    const float* bl = q.B + (size_t)min(r0 + Kp - 2 + half, rows - 1) * q.ldb + ng * 32 * NTW + 4 * l31;
+    auto afl = [&](int k0) -> float { return afn(k0 + Kp - 2); };
+    wgrad_tile_x4<1, NTW>(bl, q.ldb, 2, afl, acc);
+  } else {
+    wgrad_tile_x4<GMPC_WG_RING, NTW>(bp0, q.ldb, Kp, afn, acc);
+  }
   float* cp = part + q.part_off + (size_t)chunk * M * N;
 #pragma unroll
   for (int nt = 0; nt < NTW; ++nt) {
-    const int col = ng * 32 * NTW + nt * 32 + l31;
+    const int col = ng * 32 * NTW + (nt >> 2) * 128 + 4 * l31 + (nt & 3);
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
       const int row = mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
@@ -927,13 +994,15 @@ bool gmpc_launch_wgrad_batch(WgProb* probs, int np, float* part, long part_float
   bt.np = np;
   for (int i = 0; i < np; ++i) {
     WgProb& q = probs[i];
-    if (q.N % 256 != 0 || q.rows < 64) return false;
+    if (q.N % (32 * GMPC_WG_NTW) != 0 || q.rows < 64 || q.ldb % 4 != 0 || (reinterpret_cast<uintptr_t>(q.B) & 15) != 0)
+      return false;
     q.mstrips = (q.M + 31) / 32;
-    q.ngroups = q.N / 256;
+    q.ngroups = q.N / (32 * GMPC_WG_NTW);
   }
   // one chunk length (rows per wave-tile) for all problems, so that every wave does the same amount
   // of work: the shortest one whose partial sums fit the buffer and that needs <= 4096 wave-tiles
   static const int rpcs[] = {64, 96, 128, 192, 256, 384, 512, 768, 1024, 2048, 4096, 8192, 1 << 30};
+  static const long max_items = getenv("GMPC_WG_ITEMS") ? atol(getenv("GMPC_WG_ITEMS")) : 4096;
   int rpc = 0;
   for (int cand : rpcs) {
     long need = 0, items = 0;
@@ -943,7 +1012,7 @@ bool gmpc_launch_wgrad_batch(WgProb* probs, int np, float* part, long part_float
       need += nch * q.M * q.N + (q.colsum ? 1024L * q.N : 0);
       items += nch * q.mstrips * q.ngroups;
     }
-    if (need <= part_floats && items <= 4096) { rpc = cand; break; }
+    if (need <= part_floats && items <= max_items) { rpc = cand; break; }
   }
   if (rpc == 0) return false;
   int item = 0, cs_blocks = 0, red_blocks = 0;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
   constexpr int BM = 64 * WMT, BN = 64 * WNT;
   constexpr int VW = VEC ? 4 : 1;
   constexpr int LX = KC * BM / GMPC_THREADS / VW, LY = KC * BN / GMPC_THREADS / VW;
-  static_assert(!VEC || (KC * BM) % (4 * GMPC_THREADS) == 0 && (KC * BN) % (4 * GMPC_THREADS) == 0, "vec staging");
+  static_assert(!VEC || ((KC * BM) % (4 * GMPC_THREADS) == 0 && (KC * BN) % (4 * GMPC_THREADS) == 0), "vec staging");
   typedef typename std::conditional<VEC, float4, float>::type stage_t;
   __shared__ __attribute__((aligned(16))) float Xs[2][KC][BM];
   __shared__ __attribute__((aligned(16))) float Ys[2][KC][BN];

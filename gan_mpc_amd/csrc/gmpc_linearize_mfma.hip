@@ -46,7 +46,6 @@ __global__ __launch_bounds__(GMPC_THREADS, 1) void k_linearize_mfma(
   // `active` (the whole batch: mul 1, add 0; one time step t of every trajectory: mul T, add t)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int SK = 32 * NT + 1;
-  constexpr int NP = 32 * NT;
   constexpr int NGW = 32 * NTF;                 // columns per group of the input GEMM
   constexpr bool ONEG = NTF <= 3;               // NTF <= 3 always means a single group
   const int NGF = ONEG ? 1 : lp.NGF;
