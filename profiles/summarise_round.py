@@ -1,0 +1,37 @@
+"""Turn the output of profile_round.sh (gpurun_out/prof_<v>/) into the artefacts kept under profiles/:
+r01_<v>_bench.json, r01_<v>_bench_kernel_stats.csv, r01_<v>_bench_under_rocprof.json,
+r01_<v>_pmc_summary.md and traffic_latest.json.   usage: python profiles/summarise_round.py v12"""
+import json
+import shutil
+import sys
+
+v = sys.argv[1]
+src = f"gpurun_out/prof_{v}"
+shutil.copy(f"{src}/bench.json", f"profiles/r01_{v}_bench.json")
+shutil.copy(f"{src}/kernel_stats.csv", f"profiles/r01_{v}_bench_kernel_stats.csv")
+shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/r01_{v}_bench_under_rocprof.json")
+r = json.load(open(f"{src}/pmc_per_launch.json"))
+rows = sorted(r, key=lambda k: -r[k].get("GRBM_GUI_ACTIVE", 0))[:10]
+out = [f"# r01 {v} PMC summary (rocprofv3 --pmc, three separate passes; per launch averages)", "",
+       "Workload: `bench.py --steps 3 --warmup 1 --no-cpu-baseline --secondary-maxiter 0` (C3 shape, B=1024), one",
+       "`rocprofv3 --kernel-trace --pmc <counters> --output-format csv` run per counter set (FETCH_SIZE;",
+       "WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE), collected by `profiles/profile_round.sh`.",
+       "FETCH_SIZE / WRITE_SIZE are KiB; MFMA-busy % = MFMA_BUSY / (1,024 SIMDs x GUI_ACTIVE / 8 XCDs).", "",
+       "| kernel | FETCH KiB | WRITE KiB | MFMA_BUSY cyc (sum SIMDs) | GUI_ACTIVE (sum XCDs) | MFMA-busy % |",
+       "|---|---:|---:|---:|---:|---:|"]
+for k in rows:
+    c = r[k]
+    busy = 100 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * c["GRBM_GUI_ACTIVE"] / 8)
+    out.append(f"| `{k}` | {c.get('FETCH_SIZE', 0):.0f} | {c.get('WRITE_SIZE', 0):.0f} | "
+               f"{c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.4g} | {c['GRBM_GUI_ACTIVE']:.4g} | {busy:.1f} |")
+lin = r[[k for k in r if k.startswith("k_linearize_regs")][0]]
+traffic = int((2 * lin["FETCH_SIZE"] + lin["WRITE_SIZE"]) * 1024)
+out += ["", f"Dominant kernel HBM traffic = (2 x {lin['FETCH_SIZE']:.0f} + {lin['WRITE_SIZE']:.0f}) KiB = "
+        f"**{traffic / 1e6:.1f} MB per launch** (FETCH_SIZE doubled: 16 B/lane loads on gfx950) against 84.7 MB",
+        "algorithmic (`AB` written once, masks and weights read once)."]
+open(f"profiles/r01_{v}_pmc_summary.md", "w").write("\n".join(out) + "\n")
+json.dump({"k_linearize_hbm_bytes_per_launch": traffic,
+           "source": f"profiles/r01_{v}_pmc_summary.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                     "FETCH_SIZE doubled: 16 B/lane loads on gfx950)",
+           "algorithmic_bytes_per_launch": 84700000}, open("profiles/traffic_latest.json", "w"), indent=1)
+print("\n".join(out))
