@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="experiment: critic step on a second stream beside the backward pass")
     ap.add_argument("--secondary-maxiter", type=int, default=10,
                     help="maxiter of the secondary full-bilevel measurement (0: skip)")
     ap.add_argument("--backend", default="nccl",
@@ -196,7 +198,29 @@ def main():
     import ctypes as C
     from gan_mpc_amd import _lib
 
+    side = torch.cuda.Stream() if args.overlap else None
+
+    def step_overlap(k):
+        # experiment (--overlap): the critic step on a second stream beside the backward pass
+        main = torch.cuda.current_stream()
+        eng.rollout_cost(x0, U, goal, X=X, costs=costs)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _lib.check(eng.lib.gmpc_critic_loss_grad(
+                eng.ctx, 2 * B, C.c_void_p(xseq.data_ptr()), C.c_void_p(label.data_ptr()),
+                C.c_void_p(critic.data_ptr()), C.c_void_p(loss_view.data_ptr()),
+                C.c_void_p(grad_view.data_ptr()), eng._stream()))
+            work = dist.all_reduce(packed, async_op=True) if world > 1 else None
+        eng.lqr_backward(X, U, goal, after_rollout=True, out=bw)
+        main.wait_stream(side)
+        if work is not None:
+            work.wait()
+        eng.adam_clip_step(critic, grad_view, adam_m, adam_v, k + 1, lr=1e-5,
+                           grad_scale=1.0 / (2 * B * world))
+
     def step(k):
+        if side is not None:
+            return step_overlap(k)
         # rollout -> critic gradients -> [all-reduce in flight] backward pass -> optimiser: the only
         # exchange of the step travels over xGMI while the matrix cores run the Jacobian chain
         eng.rollout_cost(x0, U, goal, X=X, costs=costs)
