@@ -136,12 +136,70 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
   stage_t rx[LX], ry[LY];
   const int c1 = (a.K + KC - 1) / KC, c2 = (a.K2 + KC - 1) / KC, nc = c1 + c2;
   auto zero = []() { stage_t z; memset(&z, 0, sizeof(z)); return z; };
+  // Full chunks (all KC rows inside K) are staged through buffer resources: the chunk's row offset is an
+  // SGPR, each thread's element offset a loop-invariant VGPR, and a column past the edge is an offset
+  // past the resource (the load returns 0) -- no address arithmetic or predicates between the MFMAs
+  // (they were ~50 VALU instructions per 32 MFMAs; with two waves per SIMD each costs matrix-pipe time).
+  constexpr unsigned OOB = 0x7ff00000u;     // beyond any operand of one batch element (< 2 GB each)
+  const __amdgpu_buffer_rsrc_t rX1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.X + (size_t)b * a.sx), 0, (int)(((size_t)(a.K - 1) * a.ldx + a.M) * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY1 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.Y + (size_t)b * a.sy), 0, (int)(((size_t)(a.K - 1) * a.ldy + a.N) * 4), 0x00020000);
+  const bool seg2 = a.K2 > 0;
+  const __amdgpu_buffer_rsrc_t rX2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(seg2 ? a.X2 + (size_t)b * a.sx2 : a.X), 0,
+      seg2 ? (int)(((size_t)(a.K2 - 1) * a.ldx2 + a.M) * 4) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rY2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(seg2 ? a.Y2 + (size_t)b * a.sy2 : a.Y), 0,
+      seg2 ? (int)(((size_t)(a.K2 - 1) * a.ldy2 + a.N) * 4) : 0, 0x00020000);
+  unsigned vx1[LX], vx2[LX], vy1[LY], vy2[LY];
+#pragma unroll
+  for (int j = 0; j < LX; ++j) {
+    const int e = (tid + GMPC_THREADS * j) * VW, r = e / BM, c = e % BM;
+    const bool ok = m0 + c < a.M;
+    vx1[j] = ok ? (unsigned)(((size_t)r * a.ldx + m0 + c) * 4) : OOB;
+    vx2[j] = ok ? (unsigned)(((size_t)r * a.ldx2 + m0 + c) * 4) : OOB;
+  }
+#pragma unroll
+  for (int j = 0; j < LY; ++j) {
+    const int e = (tid + GMPC_THREADS * j) * VW, r = e / BN, c = e % BN;
+    const bool ok = n0 + c < a.N;
+    vy1[j] = ok ? (unsigned)(((size_t)r * a.ldy + n0 + c) * 4) : OOB;
+    vy2[j] = ok ? (unsigned)(((size_t)r * a.ldy2 + n0 + c) * 4) : OOB;
+  }
+  auto bload = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff, unsigned soff) -> stage_t {
+    stage_t out;
+    if constexpr (VEC) {
+      typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+      const v4u_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+      memcpy(&out, &q, sizeof(out));
+    } else {
+      const unsigned q = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0);
+      memcpy(&out, &q, sizeof(out));
+    }
+    return out;
+  };
   auto issue = [&](int ci) {
     const bool first = ci < c1;
+    const int K = first ? a.K : a.K2, k0 = (first ? ci : ci - c1) * KC;
+    const int ldx = first ? a.ldx : a.ldx2, ldy = first ? a.ldy : a.ldy2;
+    if (k0 + KC <= K && (size_t)K * (ldx > ldy ? ldx : ldy) * 4 < OOB) {
+      const unsigned sx_ = (unsigned)k0 * (unsigned)ldx * 4u, sy_ = (unsigned)k0 * (unsigned)ldy * 4u;
+      if (first) {
+#pragma unroll
+        for (int j = 0; j < LX; ++j) rx[j] = bload(rX1, vx1[j], sx_);
+#pragma unroll
+        for (int j = 0; j < LY; ++j) ry[j] = bload(rY1, vy1[j], sy_);
+      } else {
+#pragma unroll
+        for (int j = 0; j < LX; ++j) rx[j] = bload(rX2, vx2[j], sx_);
+#pragma unroll
+        for (int j = 0; j < LY; ++j) ry[j] = bload(rY2, vy2[j], sy_);
+      }
+      return;
+    }
     const float* X = first ? a.X + (size_t)b * a.sx : a.X2 + (size_t)b * a.sx2;
     const float* Y = first ? a.Y + (size_t)b * a.sy : a.Y2 + (size_t)b * a.sy2;
-    const int ldx = first ? a.ldx : a.ldx2, ldy = first ? a.ldy : a.ldy2;
-    const int K = first ? a.K : a.K2, k0 = (first ? ci : ci - c1) * KC;
 #pragma unroll
     for (int j = 0; j < LX; ++j) {
       const int e = (tid + GMPC_THREADS * j) * VW, r = e / BM, c = e % BM;
