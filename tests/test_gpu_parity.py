@@ -130,6 +130,21 @@ def test_critic_loss_grad(name, head):
                      gu.pack_grads_critic(g64))
 
 
+def test_critic_loss_grad_odd_row_count():
+    """An odd number of sequences times an odd T + 1: the weight-gradient GEMMs see an odd row count (81 rows,
+    chunks of 64), i.e. the clamped last k-step of k_wgrad_batch's 16-byte operand loads."""
+    pb, pb64, eng = _setup("tiny-ragged", critic=True, head_hidden=(128,))
+    d = eng.to_dev
+    rng = np.random.default_rng(9)
+    xseq = np.concatenate([pb["true_seq"], pb["goal"]], 0)[:9]      # 9 sequences x (T + 1 = 9) rows
+    label = np.where(rng.random(9) > 0.5, 1.0, -1.0).astype(np.float32)
+    ls, gs = eng.critic_loss_grad(d(xseq), d(label), d(gu.critic_flat(pb)))
+    l32, g32 = orc.critic_loss_and_grad(pb["critic"], xseq, label)
+    l64, g64 = orc.critic_loss_and_grad(pb64["critic"], xseq.astype(np.float64), label.astype(np.float64))
+    gu.assert_parity("critic loss", ls.cpu().numpy() / 9, l32, l64)
+    gu.assert_parity("critic grad", gs.cpu().numpy() / 9, gu.pack_grads_critic(g32), gu.pack_grads_critic(g64))
+
+
 @pytest.mark.parametrize("name", ["c2-cheetah", "c4-humanoid"])
 def test_critic_score_vjp(name):
     """c4-humanoid: n + F > 256, the input projection and dx run as MFMA GEMMs around the LSTM."""
