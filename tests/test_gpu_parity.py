@@ -24,6 +24,7 @@ SHAPES = {
     # chunks of the after-the-horizon cost pass), batch not a multiple of the 4 slots of a workgroup
     "rw-wide-io": (22, 9, 70, 6, dict(out_scale=0.3)),
     "rw-ragged": (17, 6, 9, 7, {}),
+    "rw-one-step": (17, 6, 1, 6, {}),          # horizon 1: the first step is the last one
     "wide": (40, 9, 6, 5, dict(dyn_hidden=(256, 64), cost_hidden=(256, 100), cost_fout=32)),
     # equal-width hidden layers of 128 / 64: the other instantiations of the register-resident chain
     "regs-128": (9, 3, 7, 11, dict(dyn_hidden=(128, 128), cost_hidden=(32,), cost_fout=4)),
@@ -180,7 +181,7 @@ def test_adam_clip_step():
         gu.assert_parity(f"adam v step {step}", vd.cpu().numpy(), v, v64)
 
 
-@pytest.mark.parametrize("name", ["tiny-ragged", "trained-like", "big-70", "rw-wide-io", "rw-ragged"])
+@pytest.mark.parametrize("name", ["tiny-ragged", "trained-like", "big-70", "rw-wide-io", "rw-ragged", "rw-one-step"])
 def test_ilqr_single_iteration_teacher_forced(name):
     """maxiter=1 from the same start: tvlqr + line search + re-linearisation, one iteration."""
     pb, pb64, eng = _setup(name)
