@@ -686,6 +686,9 @@ __global__ void k_big_cont(int B, int T, int m, const float* U, const float* gn2
 // ------------------------------------------------------------------------------------------------
 // host driver of one backward pass
 // ------------------------------------------------------------------------------------------------
+int gmpc_launch_linearize_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
+                               const uint32_t* masks, const int* active, float* AB, int samp_mul,
+                               int samp_add, hipStream_t s);
 int gmpc_launch_linearize_mfma(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
                                const uint32_t* masks, const int* active, float* AB, int samp_mul,
                                int samp_add, hipStream_t s);
@@ -719,7 +722,8 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
   };
   const int nt = (n + 31) / 32;
   for (int t = T - 1; t >= 0; --t) {
-    if (gmpc_launch_linearize_mfma(B, T, n, m, dyn, lp, masks, active, w.ABt, T, t, s) != 0) return -1;
+    if (gmpc_launch_linearize_regs(B, T, n, m, dyn, lp, masks, active, w.ABt, T, t, s) != 0 &&
+        gmpc_launch_linearize_mfma(B, T, n, m, dyn, lp, masks, active, w.ABt, T, t, s) != 0) return -1;
     const float* A = w.ABt;
     const float* Bm = w.ABt + n;
     // [PA | PB] = P [A | B]   (P symmetric, so P = P^T is the "TN" left operand)
@@ -787,7 +791,8 @@ int gmpc_big_forward_tangent(const BigWork& w, int B, const MlpDesc& dyn, const 
                              hipStream_t s) {
   const int n = w.n, m = w.m, T = w.T;
   for (int t = 0; t < T; ++t) {
-    if (gmpc_launch_linearize_mfma(B, T, n, m, dyn, lp, masks, nullptr, w.ABt, T, t, s) != 0) return -1;
+    if (gmpc_launch_linearize_regs(B, T, n, m, dyn, lp, masks, nullptr, w.ABt, T, t, s) != 0 &&
+        gmpc_launch_linearize_mfma(B, T, n, m, dyn, lp, masks, nullptr, w.ABt, T, t, s) != 0) return -1;
     hipLaunchKernelGGL(k_big_fwd, dim3(B), dim3(GMPC_THREADS), (size_t)(n + m) * sizeof(float), s, n, m, T,
                        t, w.ABt, K, k, Hout, dX);
   }

@@ -51,7 +51,12 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // odd-k one; the halves are added once per layer in the epilogue.  Two issues per k-step (rows 0..3 and
 // 4..7, 8 cycles each), no operand shuffling in the loop (a v_permlane32_swap per k-step measured 32
 // cycles of a 490-cycle k-step), the A operands -- 8 weights per k -- come from a small LDS table.
-template <int NT, int KS, int TAIL = 0>
+// WIDE: n + m > 32 (the large-state path, one time step per launch).  W_L and W_1^T no longer fit LDS: the
+// seed comes straight from the padded global copy of W_L, the input GEMM runs over the column tiles of
+// [A | B] four at a time with its weight operands through buffer loads, and the accumulator tiles -- lanes are
+// stacked rows here -- are transposed through a wave-private LDS tile so that the rows of AB are written in
+// 128-byte segments.
+template <int NT, int KS, int TAIL = 0, bool WIDE = false>
 __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linearize_regs(
     int NSamp, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
     float* AB, int ntiles, int samp_mul, int samp_add) {
@@ -62,14 +67,16 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
   const int half = lane >> 5, l31 = lane & 31;
   const int Lh = dyn.L - 1, nm = n + m;
   const int Rtot = NSamp * n;
-  const int wl_floats = (dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;
-  for (int e = threadIdx.x; e < wl_floats; e += blockDim.x) wl_s[e] = lp.WLP[e];
+  const int wl_floats = WIDE ? 4 * 32 * 33 : (dyn.dims[Lh] + GMPC_LIN_PADROWS) * n;   // WIDE: transpose tiles
+  if (!WIDE)
+    for (int e = threadIdx.x; e < wl_floats; e += blockDim.x) wl_s[e] = lp.WLP[e];
   // tail rows 32 NT .. 32 NT + 7 of every hidden W_l^T: wt_s[l - 1][k][8]
   float* wt_s = wl_s + wl_floats;
   // the padded W_1^T (2 KS x 32) of the input GEMM: one MFMA per k-step cannot hide an L2 round trip
   // per operand, an LDS read it can
   float* w1_s = wt_s + (TAIL > 0 ? (Lh - 1) * 2 * KS * 8 : 0);
-  for (int e = threadIdx.x; e < 2 * KS * 32; e += blockDim.x) w1_s[e] = lp.WTP[0][e];
+  if (!WIDE)
+    for (int e = threadIdx.x; e < 2 * KS * 32; e += blockDim.x) w1_s[e] = lp.WTP[0][e];
   if (TAIL > 0) {
     for (int l = 1; l < Lh; ++l)
       for (int e = threadIdx.x; e < 2 * KS * 8; e += blockDim.x) {
@@ -105,10 +112,10 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
       uint32_t mw[NT + 1];
 #pragma unroll
       for (int w = 0; w < NT + (TAIL > 0 ? 1 : 0); ++w) mw[w] = mrow[(Lh - 1) * GMPC_MW + w] >> half;
-      const float* wl = wl_s + half * n + irow;
+      const float* wl = (WIDE ? lp.WLP : wl_s) + half * n + irow;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const float v = wl[2 * ks * n];
+        const float v = wl[(size_t)2 * ks * n];
         S[ks] = ((mw[(2 * ks) >> 5] >> ((2 * ks) & 31)) & 1u) ? v : 0.f;
       }
     }
@@ -218,30 +225,103 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
       GMPC_STAMP(2)
     }
 
-    // ---- input GEMM  out = W_1 S_1 : rows = input coordinate c (n + m <= 32), one MFMA per k-step
-    f32x16 acc0;
+    if constexpr (WIDE) {
+      // ---- input GEMM over the column tiles of [A | B], CTW tiles per pass; rows of W_1^T (2 KS x ld0, zero
+      // padded) through a buffer resource: k-step and tile offsets are SGPRs / immediates
+      const int ld0 = 32 * lp.NTF * lp.NGF;
+      const int tilesF = (nm + 31) / 32;
+      const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<float*>(lp.WTP[0]), 0, (int)((size_t)(2 * KS + GMPC_LIN_PADROWS) * ld0 * sizeof(float)),
+          0x00020000);
+      const int voff = (half * ld0 + l31) * 4;
+      float* tb = wl_s + wave * (32 * 33);                  // this wave's transpose tile
+      // one pass: CT column tiles starting at tile t0 (tiles past the last one see the zero padding of W_1^T
+      // and are not stored)
+      auto pass = [&](auto ctc, int t0) __attribute__((always_inline)) {
+        constexpr int CT = decltype(ctc)::value;
+        f32x16 acc0[CT];
 #pragma unroll
-    for (int rg = 0; rg < 16; ++rg) acc0[rg] = 0.f;
-    {
-      const float* ap = w1_s + half * 32 + l31;
-      float a[6];
+        for (int j = 0; j < CT; ++j)
 #pragma unroll
-      for (int j = 0; j < 5; ++j) a[j] = ap[j * 64];
+          for (int rg = 0; rg < 16; ++rg) acc0[j][rg] = 0.f;
+        constexpr int RD0 = 3;
+        float aw[RD0][CT];
+        auto wload = [&](int ks_, int j_) -> float {
+          const unsigned r = __builtin_amdgcn_raw_buffer_load_b32(w1r, voff, (2 * ks_ * ld0 + (t0 + j_) * 32) * 4, 0);
+          return __uint_as_float(r);
+        };
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        if (ks + 5 < KS) a[(ks + 5) % 6] = ap[(ks + 5) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks % 6], S[ks], acc0, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < RD0 - 1; ++q)
+#pragma unroll
+          for (int j = 0; j < CT; ++j) aw[q][j] = wload(q, j);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks + RD0 - 1 < KS) {
+#pragma unroll
+            for (int j = 0; j < CT; ++j) aw[(ks + RD0 - 1) % RD0][j] = wload(ks + RD0 - 1, j);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < CT; ++j)
+            acc0[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ks % RD0][j], S[ks], acc0[j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // stores: accumulator tile j = 32 input coordinates (rows of the MFMA) x 32 stacked rows (lanes);
+        // through the LDS tile it leaves as 32 stacked rows x 32 consecutive columns
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          const int c0 = (t0 + j) * 32;
+          if (c0 < nm) {
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+              const int cl = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+              tb[l31 * 33 + cl] = acc0[j][rg] + (c0 + cl == irow ? 1.0f : 0.0f);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const int rr = 2 * i + half;
+              const float v = tb[rr * 33 + l31];
+              if (r0 + rr < Rtot && c0 + l31 < nm) AB[(size_t)(r0 + rr) * nm + c0 + l31] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+          }
+        }
+      };
+      // passes of 4 tiles, the rest in passes of 3 when that wastes less (13 tiles = 4 + 3 + 3 + 3)
+      int n4 = tilesF / 4;
+      while (n4 > 0 && (tilesF - 4 * n4) % 3 != 0) --n4;
+      if ((tilesF - 4 * n4) % 3 != 0) n4 = (tilesF + 3) / 4;      // no exact split: pad the last pass of 4
+      int t0 = 0;
+      for (int i = 0; i < n4; ++i, t0 += 4) pass(std::integral_constant<int, 4>{}, t0);
+      for (; t0 < tilesF; t0 += 3) pass(std::integral_constant<int, 3>{}, t0);
+      GMPC_STAMP(3)
+    } else {
+      // ---- input GEMM  out = W_1 S_1 : rows = input coordinate c (n + m <= 32), one MFMA per k-step
+      f32x16 acc0;
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) acc0[rg] = 0.f;
+      {
+        const float* ap = w1_s + half * 32 + l31;
+        float a[6];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) a[j] = ap[j * 64];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks + 5 < KS) a[(ks + 5) % 6] = ap[(ks + 5) * 64];
+          __builtin_amdgcn_sched_barrier(0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks % 6], S[ks], acc0, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-    }
-    GMPC_STAMP(3)
-    if (rvalid) {
-      float* dst = AB + (size_t)R * nm;
+      GMPC_STAMP(3)
+      if (rvalid) {
+        float* dst = AB + (size_t)R * nm;
 #pragma unroll
-      for (int rg = 0; rg < 16; ++rg) {
-        const int c = (rg & 3) + 8 * (rg >> 2) + 4 * half;
-        if (c < nm) dst[c] = acc0[rg] + (c == irow ? 1.0f : 0.0f);
+        for (int rg = 0; rg < 16; ++rg) {
+          const int c = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+          if (c < nm) dst[c] = acc0[rg] + (c == irow ? 1.0f : 0.0f);
+        }
       }
     }
     GMPC_STAMP(4)
@@ -251,7 +331,7 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
 #undef GMPC_STAMP
 }
 
-template <int NT, int KS, int TAIL = 0>
+template <int NT, int KS, int TAIL = 0, bool WIDE = false>
 static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
                        const uint32_t* masks, const int* active, float* AB, int samp_mul, int samp_add,
                        hipStream_t s) {
@@ -259,14 +339,15 @@ static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const
   if (Rtot >= (1L << 31) - 64) return -1;
   const int ntiles = (int)((Rtot + 31) / 32);
   const int Lh = dyn.L - 1;
-  size_t lds = (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n * sizeof(float);
+  size_t lds = WIDE ? (size_t)4 * 32 * 33 * sizeof(float)
+                    : (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n * sizeof(float);
   if (TAIL > 0) lds += (size_t)(Lh - 1) * 2 * KS * 8 * sizeof(float);
-  lds += (size_t)2 * KS * 32 * sizeof(float);
+  if (!WIDE) lds += (size_t)2 * KS * 32 * sizeof(float);
   if (lds > 64 * 1024) return -1;
   int grid = (ntiles + 3) / 4;
   constexpr int occ = GMPC_REGS_OCC(NT, TAIL);
   if (grid > 256 * occ) grid = 256 * occ;   // persistent workgroups, occ per CU
-  hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
+  hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, WIDE>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
                      dyn, lp, masks, active, AB, ntiles, samp_mul, samp_add);
   return 0;
 }
@@ -276,10 +357,17 @@ int gmpc_launch_linearize_regs(int NSamp, int T, int n, int m, const MlpDesc& dy
                                const uint32_t* masks, const int* active, float* AB, int samp_mul,
                                int samp_add, hipStream_t s) {
   const int Lh = dyn.L - 1;
-  if (Lh < 2 || n + m > 32 || lp.NTF != 1 || lp.NGF != 1) return -1;
+  if (Lh < 2) return -1;
   const int H = dyn.dims[1];
   for (int l = 1; l <= Lh; ++l)
     if (dyn.dims[l] != H) return -1;
+  if (n + m > 32) {
+    // wide inputs (large-state path): the 200-wide instantiation only
+    static const bool off = getenv("GMPC_LIN_WIDE") != nullptr && getenv("GMPC_LIN_WIDE")[0] == '0';
+    if (off || H != 200 || lp.NT != 7 || 32 * lp.NTF * lp.NGF < ((n + m + 31) / 32 + 3) / 4 * 4 * 32) return -1;
+    return launch_regs<6, 100, 8, true>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
+  }
+  if (lp.NTF != 1 || lp.NGF != 1) return -1;
   if (H == 200 && lp.NT == 7) {
     static const bool no_tail = getenv("GMPC_LIN_NOTAIL") != nullptr;
     if (!no_tail)
