@@ -268,6 +268,11 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
     }
 }
 
+// rows of X and Y per LDS stage: 16 with 16-byte staging (half the barriers per MFMA; C5 5.95 -> 5.85 s),
+// 8 with dword staging (16 there doubles the staging instructions: C4 115 -> 120 ms)
+#ifndef GMPC_BG_KC_VEC
+#define GMPC_BG_KC_VEC 16
+#endif
 #ifndef GMPC_BG_KC
 #define GMPC_BG_KC 8
 #endif
@@ -283,7 +288,7 @@ static void launch_lds(const BgemmArgs& a, hipStream_t s) {
                    al4(a.Y, a.sy, a.ldy) && al4(a.K2 ? a.X2 : nullptr, a.sx2, a.ldx2) &&
                    al4(a.K2 ? a.Y2 : nullptr, a.sy2, a.ldy2);
   if (vec)
-    hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT == 3 ? 2 : WNT, GMPC_BG_KC, true>), dim3((unsigned)(per * 8)),
+    hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT == 3 ? 2 : WNT, GMPC_BG_KC_VEC, true>), dim3((unsigned)(per * 8)),
                        dim3(GMPC_THREADS), 0, s, a);
   else
     hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT, GMPC_BG_KC>), dim3((unsigned)(per * 8)), dim3(GMPC_THREADS), 0,
