@@ -350,8 +350,9 @@ struct BigStepArgs {
 };
 
 static size_t big_step_lds(int n, int m) {
-  return ((size_t)2 * m * m + 5 * (size_t)n + 7 * (size_t)m + 16 + 2 * GMPC_THREADS +
-          (size_t)m * GMPC_THREADS + ((m & 7) == 0 ? (size_t)m * m + 4 : 0)) * sizeof(float);
+  const size_t MP = (size_t)((m + 7) & ~7);     // solve columns and the blocked solve's copies are padded to 8
+  return ((size_t)2 * m * m + 5 * (size_t)n + 7 * (size_t)m + 16 + 2 * GMPC_THREADS + MP * GMPC_THREADS +
+          ((m & 7) ? 3 : 1) * MP * MP + 4) * sizeof(float);
 }
 
 __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
@@ -493,25 +494,40 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     }
     // [K k] = -(G + delta I)^-1 [H h], one right-hand-side column per thread (column n is h); the
     // thread keeps its column in LDS (ycol[i][tid])
-    if ((m & 7) == 0) {
-      // m a multiple of 8 (C5: 64): blocks of 8 rows share the loads of the solved part of the column and read
-      // their rows of L (Lt in the backward sweep) 16 bytes at a time -- 0.4 LDS reads per multiply-subtract
-      // instead of 2 (the scalar form below spent 9.4 ms per time step of the C5 shard in this loop)
-      float* Lt = reinterpret_cast<float*>(                 // Lt[i][k] = L[k][i], 16-byte aligned
-          (reinterpret_cast<uintptr_t>(ycol + (size_t)m * GMPC_THREADS) + 15) & ~(uintptr_t)15);
-      for (int e = tid; e < m * m; e += blockDim.x) Lt[e] = L[(e % m) * m + e / m];
+    {
+      // blocks of 8 rows share the loads of the solved part of the column and read their rows of L (L^T in
+      // the backward sweep) and G 16 bytes at a time -- 0.4 LDS reads per multiply-subtract instead of 2 (the
+      // scalar form spent 9.4 ms per time step of the C5 shard in this loop).  m is padded to a multiple of
+      // 8 with an identity block (copies Lb / Ltb / Gb with row stride MP; for m % 8 == 0 L and G are used in
+      // place and only the transpose is built)
+      const int MP = (m + 7) & ~7;
+      float* xtra = reinterpret_cast<float*>(
+          (reinterpret_cast<uintptr_t>(ycol + (size_t)MP * GMPC_THREADS) + 15) & ~(uintptr_t)15);
+      float* Ltb = xtra;                                    // Ltb[i][k] = L[k][i]
+      float* Lb = (m & 7) ? xtra + MP * MP : L;
+      float* Gb = (m & 7) ? xtra + 2 * MP * MP : G;
+      for (int e = tid; e < MP * MP; e += blockDim.x) {
+        const int i = e / MP, k = e - i * MP;
+        const bool in = i < m && k < m;
+        Ltb[e] = in ? L[k * m + i] : (i == k ? 1.f : 0.f);
+        if (m & 7) {
+          Lb[e] = in ? L[i * m + k] : (i == k ? 1.f : 0.f);
+          Gb[e] = in ? G[i * m + k] : 0.f;
+        }
+      }
       __syncthreads();
       for (int c = tid; c <= n; c += blockDim.x) {
-        for (int i0 = 0; i0 < m; i0 += 8) {
+        for (int i0 = 0; i0 < MP; i0 += 8) {
           float acc[8], yb[8];
 #pragma unroll
-          for (int r = 0; r < 8; ++r) acc[r] = c < n ? HG[(size_t)(i0 + r) * nm + c] : hv[i0 + r];
+          for (int r = 0; r < 8; ++r)
+            acc[r] = i0 + r < m ? (c < n ? HG[(size_t)(i0 + r) * nm + c] : hv[i0 + r]) : 0.f;
           for (int k = 0; k < i0; k += 4) {
             const float y0 = y[(k + 0) * GMPC_THREADS], y1 = y[(k + 1) * GMPC_THREADS];
             const float y2 = y[(k + 2) * GMPC_THREADS], y3 = y[(k + 3) * GMPC_THREADS];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-              const float4 l4 = *reinterpret_cast<const float4*>(&L[(i0 + r) * m + k]);
+              const float4 l4 = *reinterpret_cast<const float4*>(&Lb[(i0 + r) * MP + k]);
               acc[r] -= l4.x * y0; acc[r] -= l4.y * y1; acc[r] -= l4.z * y2; acc[r] -= l4.w * y3;
             }
           }
@@ -519,21 +535,21 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
           for (int r = 0; r < 8; ++r) {
             float v = acc[r];
 #pragma unroll
-            for (int q = 0; q < r; ++q) v -= L[(i0 + r) * m + i0 + q] * yb[q];
-            yb[r] = v / L[(i0 + r) * m + i0 + r];
+            for (int q = 0; q < r; ++q) v -= Lb[(i0 + r) * MP + i0 + q] * yb[q];
+            yb[r] = v / Lb[(i0 + r) * MP + i0 + r];
             y[(i0 + r) * GMPC_THREADS] = yb[r];
           }
         }
-        for (int i0 = m - 8; i0 >= 0; i0 -= 8) {
+        for (int i0 = MP - 8; i0 >= 0; i0 -= 8) {
           float acc[8], xb[8];
 #pragma unroll
           for (int r = 0; r < 8; ++r) acc[r] = y[(i0 + r) * GMPC_THREADS];
-          for (int k = i0 + 8; k < m; k += 4) {
+          for (int k = i0 + 8; k < MP; k += 4) {
             const float y0 = y[(k + 0) * GMPC_THREADS], y1 = y[(k + 1) * GMPC_THREADS];
             const float y2 = y[(k + 2) * GMPC_THREADS], y3 = y[(k + 3) * GMPC_THREADS];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-              const float4 l4 = *reinterpret_cast<const float4*>(&Lt[(i0 + r) * m + k]);
+              const float4 l4 = *reinterpret_cast<const float4*>(&Ltb[(i0 + r) * MP + k]);
               acc[r] -= l4.x * y0; acc[r] -= l4.y * y1; acc[r] -= l4.z * y2; acc[r] -= l4.w * y3;
             }
           }
@@ -541,22 +557,22 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
           for (int r = 7; r >= 0; --r) {
             float v = acc[r];
 #pragma unroll
-            for (int q = r + 1; q < 8; ++q) v -= Lt[(i0 + r) * m + i0 + q] * xb[q];
-            xb[r] = v / L[(i0 + r) * m + i0 + r];
+            for (int q = r + 1; q < 8; ++q) v -= Ltb[(i0 + r) * MP + i0 + q] * xb[q];
+            xb[r] = v / Lb[(i0 + r) * MP + i0 + r];
             y[(i0 + r) * GMPC_THREADS] = xb[r];
           }
         }
         if (c < n) {
-          for (int i0 = 0; i0 < m; i0 += 8) {
+          for (int i0 = 0; i0 < MP; i0 += 8) {
             float acc[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) acc[r] = 0.f;
-            for (int k = 0; k < m; k += 4) {
+            for (int k = 0; k < MP; k += 4) {
               const float y0 = -y[(k + 0) * GMPC_THREADS], y1 = -y[(k + 1) * GMPC_THREADS];
               const float y2 = -y[(k + 2) * GMPC_THREADS], y3 = -y[(k + 3) * GMPC_THREADS];
 #pragma unroll
               for (int r = 0; r < 8; ++r) {
-                const float4 g4 = *reinterpret_cast<const float4*>(&G[(i0 + r) * m + k]);
+                const float4 g4 = *reinterpret_cast<const float4*>(&Gb[(i0 + r) * MP + k]);
                 acc[r] = fmaf(g4.x, y0, acc[r]); acc[r] = fmaf(g4.y, y1, acc[r]);
                 acc[r] = fmaf(g4.z, y2, acc[r]); acc[r] = fmaf(g4.w, y3, acc[r]);
               }
@@ -564,6 +580,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
               const int i = i0 + r;
+              if (i >= m) continue;
               const float kic = -y[i * GMPC_THREADS];
               const float vic = fmaf(0.5f, acc[r], HG[(size_t)i * nm + c]);
               Kt[(size_t)i * n + c] = kic;
@@ -576,35 +593,6 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
         } else {
           for (int i = 0; i < m; ++i) { kv[i] = -y[i * GMPC_THREADS]; a.k[bt * m + i] = -y[i * GMPC_THREADS]; }
         }
-      }
-    } else
-    for (int c = tid; c <= n; c += blockDim.x) {
-      for (int i = 0; i < m; ++i) {
-        float v = c < n ? HG[(size_t)i * nm + c] : hv[i];
-        for (int k = 0; k < i; ++k) v -= L[i * m + k] * y[k * GMPC_THREADS];
-        y[i * GMPC_THREADS] = v / L[i * m + i];
-      }
-      for (int i = m - 1; i >= 0; --i) {
-        float v = y[i * GMPC_THREADS];
-        for (int k = i + 1; k < m; ++k) v -= L[k * m + i] * y[k * GMPC_THREADS];
-        y[i * GMPC_THREADS] = v / L[i * m + i];
-      }
-      if (c < n) {
-        // K column, V = H + G K / 2 and the stacked operands [K; V], [V; K] of the cross-term product
-        // (the column is still in LDS: no global re-reads)
-        for (int i = 0; i < m; ++i) {
-          float v = 0.f;
-          for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], -y[k * GMPC_THREADS], v);
-          const float kic = -y[i * GMPC_THREADS];
-          const float vic = fmaf(0.5f, v, HG[(size_t)i * nm + c]);
-          Kt[(size_t)i * n + c] = kic;
-          KV[(size_t)i * n + c] = kic;
-          KV[(size_t)(m + i) * n + c] = vic;
-          VK[(size_t)i * n + c] = vic;
-          VK[(size_t)(m + i) * n + c] = kic;
-        }
-      } else {
-        for (int i = 0; i < m; ++i) { kv[i] = -y[i * GMPC_THREADS]; a.k[bt * m + i] = -y[i * GMPC_THREADS]; }
       }
     }
   } else {
