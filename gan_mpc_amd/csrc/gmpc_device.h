@@ -339,6 +339,42 @@ struct LinPad {
 // ---- fp32 matrix-core building block -----------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- MFMA -> vector read fence ------------------------------------------------------------------
+// gfx950 does not interlock a vector instruction that reads (or overwrites) the LAST registers of the destination of
+// an MFMA still in flight: registers 14 / 15 of v_mfma_f32_32x32x2_f32 return their OLD value for 18 wait states,
+// 2 / 3 of v_mfma_f32_16x16x4_f32 for 10, register 3 of v_mfma_f32_4x4x1_16b_f32 for 4 (the earlier registers read
+// fresh at any distance; measured with tests/repro/mfma_wait_states.hip).  hipcc (ROCm 7.2) pads for that along the
+// LAYOUT order of the basic blocks only: where a conditional branch skips a block lying between the MFMA and its
+// first reader (`if (stamps) {...}`, `if (beta != 0) {...}`), the taken path comes out short -- the cause of the
+// 3.8e-2 error of k_linearize_regs<2, 32> with the scheduling hints (tests/repro/README.md section 2).  Wherever
+// an accumulator is first read in a block a branch can reach, the kernels put this fence between the two: every
+// MFMA that writes `acc` is ordered before it, every reader after it, 18 wait states in between (volatile asm
+// statements keep their order).  tests/repro/check_mfma_hazards.py walks the ISA of every kernel for what is left.
+// AG: the accumulators live in the accumulation half of the register file ("a" registers: what hipcc picks for
+// the one-wave-per-SIMD kernels); false: in "v" registers (the 256-register, two-waves-per-SIMD kernels).  The
+// wrong choice costs a copy of every register in and out, not correctness.
+template <bool AG, typename T>
+__device__ __forceinline__ void mfma_tie(T& acc) {
+  if constexpr (AG) asm volatile("" : "+a"(acc));
+  else asm volatile("" : "+v"(acc));
+}
+template <bool AG, typename... A>
+__device__ __forceinline__ void mfma_fence(A&... acc) {
+  (mfma_tie<AG>(acc), ...);
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1");
+  (mfma_tie<AG>(acc), ...);
+}
+template <bool AG, int NT, typename... A>
+__device__ __forceinline__ void mfma_fence_tiles(f32x16 (&acc)[NT], A&... more) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) mfma_tie<AG>(acc[nt]);
+  (mfma_tie<AG>(more), ...);
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 1");
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) mfma_tie<AG>(acc[nt]);
+  (mfma_tie<AG>(more), ...);
+}
+
 // One GEMM of the chain for one 32-row tile: acc[nt] += A[32 x Kp] * B[Kp x 32*NTT].
 // bp0 points at this lane's element of B row `half` (row stride NP floats, any address space);
 // afn(k0) returns this lane's A element of k-step k0 (k = k0 + half).  B/A of k-step k0+4 are

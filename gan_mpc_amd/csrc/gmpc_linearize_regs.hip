@@ -61,6 +61,7 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
     int NSamp, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
     float* AB, int ntiles, int samp_mul, int samp_add) {
   static_assert(NT <= 8 && 2 * KS <= 32 * NT + TAIL && (TAIL == 0 || TAIL == 8), "shape");
+  constexpr bool AG = GMPC_REGS_OCC(NT, TAIL) == 1;      // register half of the accumulators (mfma_fence)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wl_s = reinterpret_cast<float*>(smem);          // W_L  [(H + pad)][n]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -182,12 +183,10 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
         // spread the two weight loads and their address arithmetic BETWEEN the MFMAs of the k-step:
         // issued as a block at the k-step boundary they do not overlap the matrix pipe (one wave per
         // SIMD), see gemm_tile_x4
-        // (only for NT >= 4: with the hints the NT = 2 instantiation fails its parity test -- reproducible,
-        // cause not isolated, ISA of both builds under tests/repro/ -- so it keeps plain program order)
-#ifndef GMPC_LIN_SGB_MIN_NT
-#define GMPC_LIN_SGB_MIN_NT 4     // -DGMPC_LIN_SGB_MIN_NT=2: the hints for every instantiation (tests/repro/README.md)
-#endif
-        if (NT >= GMPC_LIN_SGB_MIN_NT) {
+        // (round 2 kept the hints away from NT = 2, whose parity test failed with them: the reordered k-step ended on
+        // the MFMA whose last register the epilogue reads first, 12 wait states later on the path that skips the
+        // stamp block -- a stale read, not a scheduling defect; the fences below close it for every instantiation)
+        {
 #pragma unroll
           for (int i_ = 0; i_ < NT + (TAIL > 0 ? 2 : 0); ++i_) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -200,6 +199,9 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
         __builtin_amdgcn_sched_barrier(0);
       }
       GMPC_STAMP(1)
+      // the accumulators are first read behind the (skipped) stamp block: see mfma_fence in gmpc_device.h
+      if constexpr (TAIL > 0) mfma_fence_tiles<AG>(acc, acct, acct2);
+      else mfma_fence_tiles<AG>(acc);
       // epilogue: relu bits of hidden layer l-1 (rows of acc), then re-pair rows into B operands
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
             acc0[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[ks % RD0][j], S[ks], acc0[j], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
+        mfma_fence_tiles<AG>(acc0);
         // stores: accumulator tile j = 32 input coordinates (rows of the MFMA) x 32 stacked rows (lanes);
         // through the LDS tile it leaves as 32 stacked rows x 32 consecutive columns
 #pragma unroll
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
         }
       }
       GMPC_STAMP(3)
+      mfma_fence<AG>(acc0);
       if (rvalid) {
         float* dst = AB + (size_t)R * nm;
 #pragma unroll
