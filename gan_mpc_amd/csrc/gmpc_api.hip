@@ -55,6 +55,17 @@ void gmpc_launch_lstm_bwd(int, const CriticDesc&, const float*, const float*, co
 void gmpc_launch_wgrad(int, int, int, const float*, int, const float*, int, float*, float*, int,
                        float*, int, hipStream_t, long, bool);
 bool gmpc_launch_wgrad_batch(WgProb*, int, float*, long, hipStream_t);
+void gmpc_launch_colsum(int, int, const float*, int, float*, float*, hipStream_t);
+// second-generation LSTM kernels (gmpc_critic_lstm.hip): n <= 32
+bool gmpc_lstm2_supported(const CriticDesc&);
+long gmpc_lstm2_wpart_floats(const CriticDesc&, int);
+bool gmpc_launch_lstm_fwd2(int, const CriticDesc&, const float*, float*, float*, float*, float*, hipStream_t);
+bool gmpc_launch_lstm_bwd2(int, const CriticDesc&, const float*, const float*, const float*, const float*,
+                           const float*, float*, float*, float*, float*, float*, hipStream_t);
+void gmpc_launch_head2(int, const CriticDesc&, int, const float*, const float*, float*, float*, float*, float*,
+                       float*, float*, int, hipStream_t);
+void gmpc_launch_mlp_transpose_all(const MlpDesc&, hipStream_t);
+#define GMPC_HEAD2_LD 264
 void gmpc_launch_sum(int, const float*, float*, int, hipStream_t);
 void gmpc_launch_adam(long, float*, const float*, float*, float*, float, int, double, double, double,
                       double, double, float*, hipStream_t);
@@ -224,6 +235,8 @@ struct gmpc_ctx {
   int cstride;
   // critic workspace
   float *critT, *gates, *cs, *hp, *hT, *dz, *hacts, *hdels, *dhT, *cscore, *closs;
+  float* lwp = nullptr;        // weight-gradient partials of k_lstm_bwd2, one [85][256] block per 4 sequences
+  float* plast = nullptr;      // k_head2: last layer's act * dscore products and dscore, [Bc + 8][GMPC_HEAD2_LD]
   int hstride;
   LsWork lsw{};
   // large-state (n > 64) backward pass
@@ -405,7 +418,8 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
     }
   }
   if (s.lstm_features > 0) {
-    const size_t Bc = 2 * B, F = s.lstm_features, T1 = T + 1, n = c->nx;   // the critic scores x sequences
+    // (the saves of the LSTM kernels are laid out per workgroup of 4 sequences: round the batch up)
+    const size_t Bc = (2 * B + 3) / 4 * 4, F = s.lstm_features, T1 = T + 1, n = c->nx;   // the critic scores x sequences
     int hin = 0, hout = 0;
     for (int l = 0; l < s.head_layers; ++l) { hin += s.head_dims[l]; hout += s.head_dims[l + 1]; }
     c->hstride = hin > hout ? hin : hout;
@@ -420,6 +434,12 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
       A_(xT, Bc * T1 * n + 16 * Bc * T1);
       A_(xproj, (Bc * T1 + 16) * 4 * F);
     }
+    {
+      CriticDesc probe{};
+      probe.n = (int)n; probe.F = (int)F; probe.T1 = (int)T1;
+      if (gmpc_lstm2_supported(probe)) A_(lwp, gmpc_lstm2_wpart_floats(probe, (int)Bc));
+    }
+    A_(plast, (Bc + 8) * GMPC_HEAD2_LD);
     A_(hacts, (Bc + 8) * c->hstride);
     A_(hdels, (Bc + 8) * c->hstride);
     A_(dhT, Bc * F);
@@ -444,6 +464,7 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
     (void)hipMemset(c->dz, 0, ((size_t)2 * B * (T + 1) + 8) * 4 * s.lstm_features * sizeof(float));
     (void)hipMemset(c->hdels, 0, ((size_t)2 * B + 8) * c->hstride * sizeof(float));
     (void)hipMemset(c->hacts, 0, ((size_t)2 * B + 8) * c->hstride * sizeof(float));
+    (void)hipMemset(c->plast, 0, ((size_t)2 * B + 8) * GMPC_HEAD2_LD * sizeof(float));
   }
   if (!rc) (void)hipMemset(c->Ks, 0, (B * T * m * n + 16 * nm) * sizeof(float));
   if (rc) {
@@ -580,6 +601,19 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     HIP_TRY(hipGetLastError());
     return 0;
   }
+  // The terminal quadratisation needs X only: it runs BEFORE the Jacobian chain, so that the Riccati sweep is the
+  // launch right behind the chain.  With the critic step on a second stream gated by lin_event, the sweep's
+  // one-wave workgroups are then dispatched first and take the low end of every SIMD's register file; launched
+  // 0.03 ms later (behind k_terminal) they landed BETWEEN the critic's waves, and the 272-register waves of
+  // k_lstm_bwd2 found no contiguous block until the sweep had finished (0.105 -> 0.24 ms for that kernel).
+  static const bool terminal_first = !(getenv("GMPC_TERMINAL_FIRST") && getenv("GMPC_TERMINAL_FIRST")[0] == '0');
+  auto run_terminal = [&]() -> int {
+    ProfScope ps(c, PROF_TERMINAL, s);
+    if (gmpc_launch_terminal(B, sh.T, sh.n, c->cost, c->mpc_w, X, active, c->QT, c->qT, s) != 0)
+      return fail(GMPC_EINVAL, "terminal: unsupported fout");
+    return 0;
+  };
+  if (terminal_first) TRY(run_terminal());
   {
     ProfScope ps(c, PROF_LINEARIZE, s);
     // matrix-core chain; the VALU chain only serves shapes the MFMA tiling does not cover (or
@@ -603,11 +637,7 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
   }
   HIP_TRY(hipGetLastError());
   if (c->lin_event) HIP_TRY(hipEventRecord(c->lin_event, s));     // gmpc_set_linearize_event
-  {
-    ProfScope ps(c, PROF_TERMINAL, s);
-    if (gmpc_launch_terminal(B, sh.T, sh.n, c->cost, c->mpc_w, X, active, c->QT, c->qT, s) != 0)
-      return fail(GMPC_EINVAL, "terminal: unsupported fout");
-  }
+  if (!terminal_first) TRY(run_terminal());
   HIP_TRY(hipGetLastError());
   RiccatiArgs r;
   memset(&r, 0, sizeof(r));
@@ -765,8 +795,11 @@ static int bind_critic(gmpc_ctx* c, const float* critic, CriticDesc& cd, hipStre
   cd.b = critic + (n + F) * 4 * F;
   bind_mlp(cd.head, sh.head_layers, sh.head_dims, critic + (n + F) * 4 * F + 4 * F,
            c->critT + (n + F) * 4 * F);
-  gmpc_launch_transpose((int)(n + F), (int)(4 * F), cd.Wcat, c->critT, s);
-  transpose_mlp(cd.head, s);
+  // the first-generation LSTM kernels read [Wx; Wh]^T; the second generation (n <= 32) and the head's forward
+  // layers read the parameters as they lie, the head's backward layers its transposed kernels (one launch)
+  if (!(c->lwp != nullptr && gmpc_lstm2_supported(cd)) || c->xT != nullptr)
+    gmpc_launch_transpose((int)(n + F), (int)(4 * F), cd.Wcat, c->critT, s);
+  gmpc_launch_mlp_transpose_all(cd.head, s);
   return 0;
 }
 
@@ -796,7 +829,11 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     cr.WcatT = c->WhT;
     gmpc_launch_transpose(F, G4w, cr.Wcat, c->WhT, s);
   }
-  {
+  const bool gen2 = !widein && c->lwp != nullptr && gmpc_lstm2_supported(cd);
+  if (gen2) {
+    ProfScope ps(c, PROF_LSTM_FWD, s);
+    gmpc_launch_lstm_fwd2(Bc, cd, xseq, c->gates, c->cs, c->hp, c->hT, s);
+  } else {
     ProfScope ps(c, PROF_LSTM_FWD, s);
     if (widein) {
       gmpc_launch_transpose(R, n, xseq, c->xT, s);                       // [R][n] -> [n][R]
@@ -806,10 +843,18 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
   }
   {
     ProfScope ps(c, PROF_HEAD, s);
-    gmpc_launch_head(Bc, cd, loss_kind, c->hT, label, c->cscore, c->closs, c->hacts, c->hdels, c->dhT,
-                     c->hstride, s);
+    gmpc_launch_head2(Bc, cd, loss_kind, c->hT, label, c->cscore, c->closs, c->hacts, c->hdels, c->plast, c->dhT,
+                      c->hstride, s);
   }
-  if (dxseq || want_wgrad) {
+  float* gWx0 = grad_sum;
+  if (gen2 && (dxseq || want_wgrad)) {
+    // backward sweep with the LSTM weight gradients accumulated in registers (no dz in memory), then the
+    // reduction of the per-workgroup partials straight into grad_sum
+    ProfScope ps(c, PROF_LSTM_BWD, s);
+    float* gWh0 = want_wgrad ? gWx0 + (long)n * 4 * F : nullptr;
+    gmpc_launch_lstm_bwd2(Bc, cd, xseq, c->gates, c->cs, c->hp, c->dhT, want_wgrad ? c->lwp : nullptr, gWx0, gWh0,
+                          want_wgrad ? gWh0 + (long)F * 4 * F : nullptr, dxseq, s);
+  } else if (dxseq || want_wgrad) {
     ProfScope ps(c, PROF_LSTM_BWD, s);
     if (!widein) {
       gmpc_launch_lstm_bwd(Bc, cd, c->gates, c->cs, c->dhT, want_wgrad ? c->dz : nullptr, dxseq, s);
@@ -845,13 +890,21 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
       if (N % 256 == 0 && r >= 64 && np < GMPC_WG_MAX) add(r, M, N, A, lda, Bm, ldb, Cw, cs, cs_rows);
       else single[ns++] = Single{r, M, N, A, lda, Bm, ldb, Cw, cs, cs_rows};
     };
-    route(rows, n, G4, xseq, n, c->dz, G4, gWx, nullptr, 0);
-    route(rows, F, G4, c->hp, F, c->dz, G4, gWh, gb, rows);
+    if (!gen2) {
+      route(rows, n, G4, xseq, n, c->dz, G4, gWx, nullptr, 0);
+      route(rows, F, G4, c->hp, F, c->dz, G4, gWh, gb, rows);
+    }
     float* gh = gb + G4;
     int aoff = 0, doff = 0;
     for (int l = 0; l < sh.head_layers; ++l) {
       const int M = sh.head_dims[l], N = sh.head_dims[l + 1];
-      route(Bc, M, N, c->hacts + aoff, c->hstride, c->hdels + doff, c->hstride, gh, gh + (long)M * N, Bc);
+      if (l == sh.head_layers - 1 && np < GMPC_WG_MAX) {
+        // the last layer has one output: its weight gradient and its bias gradient are the column sums of
+        // k_head2's products [act * dscore | dscore] -- a problem without a GEMM part (M = 0)
+        add(Bc, 0, M + 1, c->plast, GMPC_HEAD2_LD, c->plast, GMPC_HEAD2_LD, gh, gh, Bc);
+      } else {
+        route(Bc, M, N, c->hacts + aoff, c->hstride, c->hdels + doff, c->hstride, gh, gh + (long)M * N, Bc);
+      }
       gh += (long)M * N + N;
       aoff += M;
       doff += N;
@@ -862,10 +915,14 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
                               pr[i].colsum, pr[i].cs_rows};
     }
     // the rest one by one, after the batch (they reuse the partial-sum buffer: stream order)
-    for (int i = 0; i < ns; ++i)
-      gmpc_launch_wgrad(single[i].r, single[i].M, single[i].N, single[i].A, single[i].lda, single[i].Bm,
-                        single[i].ldb, single[i].Cw, single[i].cs, single[i].csr, c->wpart, 256, s,
-                        c->wpart_floats, true);
+    for (int i = 0; i < ns; ++i) {
+      if (single[i].M == 0)
+        gmpc_launch_colsum(single[i].csr, single[i].N, single[i].Bm, single[i].ldb, single[i].cs, c->wpart, s);
+      else
+        gmpc_launch_wgrad(single[i].r, single[i].M, single[i].N, single[i].A, single[i].lda, single[i].Bm,
+                          single[i].ldb, single[i].Cw, single[i].cs, single[i].csr, c->wpart, 256, s,
+                          c->wpart_floats, true);
+    }
   }
   HIP_TRY(hipGetLastError());
   return 0;

@@ -990,6 +990,17 @@ __global__ __launch_bounds__(256) void k_reduce_batch(WgBatch bt, const float* p
   if (seg == 0 && e < count) out[e] = (sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el]);
 }
 
+// colsum[N] = sum_{r < rows} B[r][:N] on its own (two launches; `part` holds the chunk sums)
+void gmpc_launch_colsum(int rows, int N, const float* Bm, int ldb, float* colsum, float* part, hipStream_t s) {
+  int cchunks = (rows + 63) / 64;
+  if (cchunks > 2048) cchunks = 2048;
+  if (cchunks < 1) cchunks = 1;
+  const int crpc = (rows + cchunks - 1) / cchunks;
+  cchunks = (rows + crpc - 1) / crpc;
+  hipLaunchKernelGGL(k_colsum, dim3(cchunks), dim3(GMPC_THREADS), 0, s, rows, N, Bm, ldb, crpc, part);
+  hipLaunchKernelGGL(k_reduce_splits, dim3((N + 63) / 64), dim3(256), 0, s, N, cchunks, part, colsum);
+}
+
 // returns false when a problem does not qualify (the caller then issues them one by one)
 bool gmpc_launch_wgrad_batch(WgProb* probs, int np, float* part, long part_floats, hipStream_t s) {
   if (np < 1 || np > GMPC_WG_MAX) return false;
@@ -997,6 +1008,11 @@ bool gmpc_launch_wgrad_batch(WgProb* probs, int np, float* part, long part_float
   bt.np = np;
   for (int i = 0; i < np; ++i) {
     WgProb& q = probs[i];
+    if (q.M == 0 && q.colsum != nullptr) {      // column sums only (no GEMM part)
+      q.mstrips = 0;
+      q.ngroups = 0;
+      continue;
+    }
     if (q.N % (32 * GMPC_WG_NTW) != 0 || q.rows < 64 || q.ldb % 4 != 0 || (reinterpret_cast<uintptr_t>(q.B) & 15) != 0)
       return false;
     q.mstrips = (q.M + 31) / 32;
