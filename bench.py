@@ -14,9 +14,14 @@ is one rank; started bare, it launches `python -m torch.distributed.run --nproc-
 as a child BEFORE touching the GPU, relays rank 0's JSON line and exits with the child's code.
 weak scaling: 1024 trajectories per GPU; strong: the 1024-trajectory batch split N ways.  The only
 exchange is one all-reduce of the packed critic [loss | grads | count] buffer through
-gan_mpc_amd/parallel.py -- the same two calls the trainers use -- started before the backward pass and
-finished after it, so it travels over xGMI while the matrix cores run the Jacobian chain.
-Rank 0 prints ONE JSON line.
+gan_mpc_amd/parallel.py -- the same two calls the trainers use.  Two streams (small-state workloads): the critic
+step runs on a second stream gated behind the Jacobian chain, i.e. beside the Riccati sweep; its all-reduce is
+started on that stream as soon as the last gradient kernel is enqueued and finished before the optimiser step,
+so what hides it is whatever the Riccati sweep still has to run when the critic's kernels are through (both
+chains take about 0.35 ms side by side: on one GPU nothing is exchanged; the RCCL path with N > 1 has not run on
+hardware yet).
+Rank 0 prints ONE JSON line; `ms_per_step` / `value` are the contract's single timed window of K steps,
+`windows` gives median / min / max over that window and four more of the same length.
 """
 
 import argparse
@@ -215,6 +220,11 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=0, help="trajectories of the C baseline (0: the workload's batch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-step", default="",
+                    help="rank 0 saves the last step's all-reduced [mean loss | mean critic gradient] and the critic "
+                         "parameters to this .npz (tests/test_gpu_multirank.py: N ranks against one)")
+    ap.add_argument("--windows", type=int, default=5,
+                    help="timed windows of --steps steps each (the first one is the contract's: value / ms_per_step)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="everything on one stream (default: the critic step runs on a second stream beside the "
                          "Riccati sweep, gated behind the Jacobian chain by gmpc_set_linearize_event)")
@@ -349,6 +359,20 @@ def main():
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
     value = global_B * args.steps / dt
+    # spread: four more windows of the same length (every rank runs them: they contain the collective)
+    win = [ms_per_step]
+    for wi in range(args.windows - 1):
+        sync()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + args.steps * (wi + 1) + k)
+        sync()
+        dw = time.perf_counter() - t1
+        if world > 1:
+            tw = torch.tensor([dw], device="cuda")
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            dw = float(tw.item())
+        win.append(dw / args.steps * 1e3)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream
     roof = None
@@ -364,7 +388,7 @@ def main():
         eng.profile_enable(False)
         dom = max(prof, key=lambda kk: prof[kk][0])
         if n <= 64:
-            kname = "k_linearize"
+            kname = eng.profile_kernel_name("linearize") or "k_linearize"
             ms, cnt = prof["linearize"]
             flops = linearize_flops_per_sample(n, m, dyn_dims) * B * T
         else:
@@ -464,6 +488,19 @@ def main():
                              "algorithmic_mflop_per_candidate": round(roll_flops / 1e6, 3),
                              "linesearch_ms_total": round(ls_ms, 2), "linesearch_calls": ls_cnt}}
 
+    # replicas: every rank applied the same all-reduced gradient with the same fused clip+Adam -- the parameter
+    # vectors must be bitwise identical (checked on every multi-rank run, it costs one small all-gather)
+    if world > 1:
+        mine = critic.detach().clone()
+        allp = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        if not all(torch.equal(allp[0], q) for q in allp[1:]):
+            raise SystemExit("bench.py: the critic parameter replicas diverged across ranks")
+    if args.dump_step and rank == 0:
+        torch.cuda.synchronize()
+        np.savez(args.dump_step, mean=(packed * inv_count).cpu().numpy(), critic=critic.cpu().numpy(),
+                 world=world, global_batch=global_B)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, w)
@@ -480,6 +517,8 @@ def main():
                        "horizon": T, "state_dim": n, "act_dim": m,
                        "parallelism": f"trajectory-sharded x{world} ({args.scaling} scaling, backend "
                                       f"{args.backend if world > 1 else 'none'}), 1 all-reduce of critic grads/step"},
+            "windows": {"n": len(win), "steps_each": args.steps, "ms_per_step_median": round(float(np.median(win)), 4),
+                        "ms_per_step_min": round(min(win), 4), "ms_per_step_max": round(max(win), 4)},
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(out))

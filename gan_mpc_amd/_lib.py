@@ -93,6 +93,7 @@ SIGNATURES = {
     "gmpc_profile_enable": (C.c_int, [_P, C.c_int]),
     "gmpc_set_linearize_event": (C.c_int, [_P, _P]),
     "gmpc_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "gmpc_profile_kernel_name": (C.c_char_p, [_P, C.c_int]),
     "gmpc_debug_buffer": (_P, [_P, C.c_int]),
     "gmpc_debug_buffer_count": (C.c_long, [_P, C.c_int]),
 }

@@ -25,6 +25,7 @@ int gmpc_launch_linearize_regs(int, int, int, int, const MlpDesc&, const LinPad&
                                const int*, float*, int, int, hipStream_t);
 int gmpc_launch_linearize_mfma(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
                                const int*, float*, int, int, hipStream_t);
+const char* gmpc_linearize_regs_last_name();
 void gmpc_launch_bgemm_tn(const BgemmArgs&, hipStream_t);
 size_t gmpc_dynfit_stride(const gmpc_shape*);
 int gmpc_launch_dynfit(int, int, int, int, const MlpDesc&, const float*, const float*, const float*, float,
@@ -252,6 +253,7 @@ struct gmpc_ctx {
   // optional per-kernel timing with HIP events on the launch stream (gmpc_profile_*)
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[GMPC_PROF_SLOTS];
+  const char* lin_kernel = "";      // kernel the last Jacobian chain ran on (gmpc_profile_kernel_name)
   hipEvent_t lin_event = nullptr;   // caller's event, recorded after the Jacobian chain (gmpc_set_linearize_event)
 };
 
@@ -626,13 +628,18 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     // LDS-operand chain (any shape), 3rd: VALU
     if (c->dynl) {
       gmpc_launch_dynl_jac(B, sh.T, sh.T, 0, c->dl, X, U, active, AB, s);
+      c->lin_kernel = "k_dynl_jac";
     } else if (force == 0 && gmpc_launch_linearize_regs(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active,
                                                  AB, 1, 0, s) == 0) {
+      c->lin_kernel = gmpc_linearize_regs_last_name();
     } else if (force == 2 ||
         gmpc_launch_linearize_mfma(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active, AB, 1, 0,
                                    s) != 0) {
       if (gmpc_launch_linearize(B, sh.T, sh.n, sh.m, c->dyn, c->masks, active, AB, s) != 0)
         return fail(GMPC_EINVAL, "linearize: unsupported row count for n=%d", sh.n);
+      c->lin_kernel = "k_linearize (vector ALU)";
+    } else {
+      c->lin_kernel = "k_linearize_mfma";
     }
   }
   HIP_TRY(hipGetLastError());
@@ -1401,6 +1408,11 @@ extern "C" int gmpc_profile_enable(gmpc_ctx* c, int on) {
   if (!c) return fail(GMPC_EINVAL, "ctx is null");
   c->prof = on != 0;
   return 0;
+}
+
+extern "C" const char* gmpc_profile_kernel_name(gmpc_ctx* c, int slot) {
+  if (!c || slot != PROF_LINEARIZE) return "";
+  return c->lin_kernel;
 }
 
 extern "C" int gmpc_profile_read(gmpc_ctx* c, int slot, double* total_ms, int* count) {

@@ -47,9 +47,17 @@ __device__ __forceinline__ void transpose_rows4(float (&v)[4]) {
   swap16_(v[2], v[3]);
 }
 
-// sigmoid, and tanh as 2 sigmoid(2 x) - 1: one code path for the four gate rows of a wave
+// sigmoid, and tanh as 2 sigmoid(2 x) - 1: one code path for the four gate rows of a wave.  exp and the reciprocal
+// are the hardware's v_exp_f32 / v_rcp_f32 (1 ulp each; 4 instructions per value instead of ~25 for expf and an
+// IEEE division: the sweep is a latency chain and these sit on it five times per step).  GMPC_LSTM2_EXACT_ACT=1 at
+// build time restores expf and the division (A/B of the parity figures).
 __device__ __forceinline__ float gate_act(float x, float aa, float cc) {
+#ifdef GMPC_LSTM2_EXACT_ACT
   return fmaf(aa, 1.0f / (1.0f + expf(-aa * x)), cc);
+#else
+  const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * aa * x);
+  return fmaf(aa, __builtin_amdgcn_rcpf(1.0f + e), cc);
+#endif
 }
 
 #define GMPC_LSTM2_ROWS(NX) (((64 + (NX) + 3) / 4) * 4 + 1)    // rows of a workgroup's weight-gradient partial
@@ -707,8 +715,10 @@ void gmpc_launch_mlp_transpose_all(const MlpDesc& d, hipStream_t s) {
 int gmpc_head2_rows() {
   static const int g = [] {
     const char* e = getenv("GMPC_HEAD_G");
-    const int v = e ? atoi(e) : 3;
-    return v >= 2 && v <= 4 ? v : 3;
+    // rows per workgroup = 4 G.  Measured (C3, 2048 sequences, head 3 x 256, alone): G = 2 0.049 ms, 3 0.056, 4 0.063 --
+    // the layer chain is latency-bound per workgroup, more workgroups beat more rows per weight load
+    const int v = e ? atoi(e) : 2;
+    return v >= 2 && v <= 4 ? v : 2;
   }();
   return 4 * g;
 }

@@ -196,22 +196,29 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
     // (a chunk that runs past row K - 1 needs no other path: those rows lie beyond the buffer resources, whose
     // loads return 0)
     if ((size_t)(K + KC) * (ldx > ldy ? ldx : ldy) * 4 < OOB) {
-      const unsigned sx_ = (unsigned)k0 * (unsigned)ldx * 4u, sy_ = (unsigned)k0 * (unsigned)ldy * 4u;
+      // A full chunk lies inside the resource whatever the range check looks at, so its row offset may ride in
+      // the scalar offset (no VALU address arithmetic between the MFMAs).  The chunk that runs past row K - 1
+      // RELIES on the range check: there the whole byte offset goes into the per-lane part, which the check is
+      // documented to cover -- the scalar offset is not (it is covered on gfx950, which is how the first version
+      // of this path passed its tests; nothing here depends on that any more).
+      const bool tail = k0 + KC > K;         // wave-uniform
+      const unsigned ox = (unsigned)k0 * (unsigned)ldx * 4u, oy = (unsigned)k0 * (unsigned)ldy * 4u;
+      const unsigned sx_ = tail ? 0u : ox, sy_ = tail ? 0u : oy, ax = tail ? ox : 0u, ay = tail ? oy : 0u;
       if (sg == 0) {
 #pragma unroll
-        for (int j = 0; j < LX; ++j) rx[j] = bload(rX1, vx1[j], sx_);
+        for (int j = 0; j < LX; ++j) rx[j] = bload(rX1, vx1[j] + ax, sx_);
 #pragma unroll
-        for (int j = 0; j < LY; ++j) ry[j] = bload(rY1, vy1[j], sy_);
+        for (int j = 0; j < LY; ++j) ry[j] = bload(rY1, vy1[j] + ay, sy_);
       } else if (sg == 1) {
 #pragma unroll
-        for (int j = 0; j < LX; ++j) rx[j] = bload(rX2, vx2[j], sx_);
+        for (int j = 0; j < LX; ++j) rx[j] = bload(rX2, vx2[j] + ax, sx_);
 #pragma unroll
-        for (int j = 0; j < LY; ++j) ry[j] = bload(rY2, vy2[j], sy_);
+        for (int j = 0; j < LY; ++j) ry[j] = bload(rY2, vy2[j] + ay, sy_);
       } else {
 #pragma unroll
-        for (int j = 0; j < LX; ++j) rx[j] = bload(rX3, vx3[j], sx_);
+        for (int j = 0; j < LX; ++j) rx[j] = bload(rX3, vx3[j] + ax, sx_);
 #pragma unroll
-        for (int j = 0; j < LY; ++j) ry[j] = bload(rY3, vy3[j], sy_);
+        for (int j = 0; j < LY; ++j) ry[j] = bload(rY3, vy3[j] + ay, sy_);
       }
       return;
     }

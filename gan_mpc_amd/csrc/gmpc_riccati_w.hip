@@ -18,6 +18,16 @@
 
 typedef float f32x16_w __attribute__((ext_vector_type(16)));
 
+// The workgroup is ONE wave: its LDS instructions execute in program order, so a value written by one lane is
+// there for the lane that reads it later -- what is needed between two phases is only that hipcc keeps them in
+// order.  __syncthreads() also drains the vector-memory counter (the next step's prefetch, the K / k / gradient
+// stores of this one: a round trip to the Infinity Cache or HBM at every one of the step's 12 phase boundaries).
+#ifdef GMPC_RICCATI_W_BARRIERS
+#define RW_SYNC() __syncthreads()
+#else
+#define RW_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
 template <int N_, int M_>
 __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
   constexpr int n = N_, m = M_, nm = n + m, LD = 32;
@@ -38,7 +48,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
 
   for (int e = lane; e < NR * LD; e += 64) { Xs[e] = 0.f; Ps[e] = 0.f; Ws[e] = 0.f; }
   for (int e = lane; e < 2 * m * LD; e += 64) { KVs[e] = 0.f; VKs[e] = 0.f; }
-  __syncthreads();
+  RW_SYNC();
   for (int e = lane; e < n * n; e += 64) Ps[(e / n) * LD + e % n] = a.QT[(size_t)b * n * n + e];
   if (lane < n) {
     const float q = a.qT[(size_t)b * n + lane];
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
   };
   prefetch(T - 1);
   commit();
-  __syncthreads();
+  RW_SYNC();
 
   for (int t = T - 1; t >= 0; --t) {
     const size_t bt = (size_t)b * T + t;
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
       const int row = (rg & 3) + 8 * (rg >> 2) + 4 * half;
       if (row < NR) Ws[row * LD + l31] = acc[rg];          // (rows n .. NR - 1 come out zero: P's padding)
     }
-    __syncthreads();
+    RW_SYNC();
     // ---- Z = [A | B]^T W
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
@@ -141,19 +151,19 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
         else if (l31 < nm) Gr[(row - n) * m + l31 - n] = acc[rg];
       }
     }
-    __syncthreads();
+    RW_SYNC();
     // ---- G = sym(R + G_r), Cholesky of G + delta I, [K k] = -(G + delta I)^-1 [H h]
     if (lane < m * m) {
       const int i = lane / m, j = lane - i * m;
       const float Rij = w0 * ((i == j ? isu : 0.f) - uv[i] * uv[j] * isu3);
       Gp[lane] = Rij + Gr[lane];
     }
-    __syncthreads();
+    RW_SYNC();
     if (lane < m * m) {
       const int i = lane / m, j = lane - i * m;
       G[lane] = (Gp[lane] + Gp[j * m + i]) * 0.5f;
     }
-    __syncthreads();
+    RW_SYNC();
     if (lane == 0) {
       float Lr[m][m];
 #pragma unroll
@@ -176,7 +186,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
 #pragma unroll
         for (int j = 0; j <= i; ++j) Lc[i * m + j] = Lr[i][j];
     }
-    __syncthreads();
+    RW_SYNC();
     if (lane <= n) {
       const int c = lane;
       float Lr[m][m], y[m];
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
 #pragma unroll
       for (int i = 0; i < m; ++i) Kk[i * LD + c] = -y[i];      // column n: k_t
     }
-    __syncthreads();
+    RW_SYNC();
     // ---- outputs K_t, k_t; H + G K; the stacked operands [K; V], [V; K]
     for (int e = lane; e < m * n; e += 64) {
       const int i = e / n, j = e - i * n;
@@ -217,7 +227,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
       VKs[i * LD + j] = vv;  VKs[(m + i) * LD + j] = kij;
     }
     if (a.k && lane < m) a.k[bt * m + lane] = Kk[lane * LD + n];
-    __syncthreads();
+    RW_SYNC();
     // ---- S = A^T P A + K^T V + V^T K  (the accumulator still holds Z), P = Q_t + sym(S)
 #pragma unroll
     for (int kk = 0; kk < m; ++kk)
@@ -239,7 +249,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
       }
       pn = ((qv[lane] + Ap[lane]) + v1) + v2;
     }
-    __syncthreads();
+    RW_SYNC();
     for (int e = lane; e < n * n; e += 64) {
       const int i = e / n, j = e - i * n;
       const float Qij = w1 * ((i == j && i < ng ? is : 0.f) - dv[i] * dv[j] * is3);
@@ -251,9 +261,9 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
       lam[lane] = ln;
       if (a.adj) a.adj[((size_t)b * (T + 1) + t) * n + lane] = ln;
     }
-    __syncthreads();                               // (dv, uv, Xs of this step are dead)
+    RW_SYNC();                               // (dv, uv, Xs of this step are dead)
     if (t > 0) commit();
-    __syncthreads();
+    RW_SYNC();
   }
 
   if (a.cont != nullptr) {

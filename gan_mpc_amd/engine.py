@@ -293,6 +293,11 @@ class Engine:
             out[name] = (ms.value, cnt.value)
         return out
 
+    def profile_kernel_name(self, slot_name):
+        """Name of the kernel the slot's last launch ran on ('' when the slot has one kernel only)."""
+        name = self.lib.gmpc_profile_kernel_name(self.ctx, self.PROF_SLOTS.index(slot_name))
+        return name.decode() if name else ""
+
     def debug_buffer(self, which, shape):
         """Copy of one of the ctx's internal solution buffers (see gmpc_debug_buffer)."""
         p = self.lib.gmpc_debug_buffer(self.ctx, which)

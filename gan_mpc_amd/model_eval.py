@@ -47,7 +47,8 @@ def get_cost(horizon, xc, u, t, cost_params, mpc_weights, goal_X):
     x, single = _rows(xc, n)
     uu = np.asarray(u, np.float32).reshape(x.shape[0], -1)
     m = uu.shape[1]
-    ng = np.shape(goal_X)[-1]
+    # (the terminal branch reads no goal: goal_X may be None there, like the NULL goal_row of gmpc_get_cost)
+    ng = n if goal_X is None else np.shape(goal_X)[-1]
     if ng == n:
         eng = _engine(n, m, 1, [n + m, 1, n], cost_dims, batch=x.shape[0])
         dyn_count = _count([n + m, 1, n])
@@ -61,6 +62,8 @@ def get_cost(horizon, xc, u, t, cost_params, mpc_weights, goal_X):
                    d(np.zeros(dyn_count, np.float32)), d(P.pack_mlp(cost_params)))
     terminal = int(t) == int(horizon)
     goal_row = None
+    if not terminal and goal_X is None:
+        raise ValueError("get_cost: the staging branch (t < horizon) needs goal_X")
     if not terminal:
         g = np.asarray(goal_X, np.float32)
         goal_row = d(g[int(t)][None] if g.ndim == 2 else g[:, int(t)])

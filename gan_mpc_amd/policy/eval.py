@@ -30,8 +30,8 @@ class LqrBlock:
         return full if self._index is None else full[1:]
 
     def __getitem__(self, i):
-        if self._index is not None:
-            return self.tensor()[i]
+        if self._index is not None or not isinstance(i, (int, np.integer)):
+            return self.tensor()[i]          # slices, tuples, masks: plain tensor indexing
         if not -self._batch <= i < self._batch:
             raise IndexError(i)
         return LqrBlock(self._engine, self._batch, i % self._batch)

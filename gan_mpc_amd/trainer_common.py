@@ -28,7 +28,12 @@ def sgd_pass(policy, opt, opt_state, params, schedule, loss_and_grad):
     for batch in schedule:
         lo, hi = parallel.shard_range(len(batch))
         loss, grads = loss_and_grad(batch[lo:hi])
-        params, opt_state = opt.update(policy._engine, params, grads, opt_state)
+        # the optimiser step runs on EVERY rank, also on one whose shard of this minibatch was empty and that
+        # therefore built no engine inside the loss (minibatch smaller than the world): make sure there is one
+        eng = policy._engine
+        if eng is None:
+            eng = policy.engine_for(1, policy.to_device_params(params))
+        params, opt_state = opt.update(eng, params, grads, opt_state)
         total += float(loss)
         steps += 1
     # datasize < batch_size leaves no minibatch: the reference's mean over an empty scan is NaN

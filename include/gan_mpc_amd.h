@@ -278,6 +278,10 @@ int gmpc_set_linearize_event(gmpc_ctx* ctx, void* hip_event);
  * of launches of that slot since the last read, and resets the slot. */
 int gmpc_profile_enable(gmpc_ctx* ctx, int on);
 int gmpc_profile_read(gmpc_ctx* ctx, int slot, double* total_ms, int* count);
+/* Name of the kernel the slot's last launch ran on, as it appears in a rocprofv3 kernel trace (slot 1, the
+ * Jacobian chain: the instantiation the shape selected, e.g. "k_linearize_regs<6, 100, 8, false>"); "" for slots
+ * that always run the same kernel.  Static storage, valid until the next launch. */
+const char* gmpc_profile_kernel_name(gmpc_ctx* ctx, int slot);
 
 /* Device pointers into the ctx's solution of the last gmpc_ilqr_solve / gmpc_bilevel_grad (valid
  * until the next such call): 0 X, 1 U, 2 H = A^-1 B, 3 dX, 4 Bvec, 5 AB, 6 K, 7 k, 11 d loss / d X.

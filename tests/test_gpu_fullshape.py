@@ -124,13 +124,23 @@ def test_critic_step_full_shape(name):
             assert np.isfinite(X).all()
         xseq = np.concatenate([pb["true_seq"], X], 0)
         label = np.concatenate([np.ones(B), -np.ones(B)]).astype(np.float32)
-        ls, gs = eng.critic_loss_grad(d(xseq), d(label), d(gu.critic_flat(pb)))
         cr64 = orc.cast_problem(dict(c=pb["critic"]), np.float64)["c"]
+        # The batch gradient sums over 2B x 768 relu decisions of the head: a sequence whose pre-activation sits
+        # within 3e-6 (relative) of a kink flips its mask on a 1e-7 perturbation of h_T and moves the sum by a finite
+        # amount (hard part iii).  Such sequences -- a handful of the 2048 -- are left out of
+        # the batch, for the kernels and for both oracles alike, exactly as the Jacobian tests leave out samples.
+        with np.errstate(over="ignore"):
+            _, saved = orc.critic_forward(cr64, xseq.astype(np.float64), keep=True)
+        keep = ~gu.near_kink(cr64["head"][:-1], saved[1]) if len(cr64["head"]) > 1 else np.ones(2 * B, bool)
+        assert keep.sum() >= 0.98 * 2 * B, f"{(~keep).sum()} of {2 * B} sequences near a relu kink"
+        xseq, label = xseq[keep], label[keep]
+        Bc = int(keep.sum())
+        ls, gs = eng.critic_loss_grad(d(xseq), d(label), d(gu.critic_flat(pb)))
         with np.errstate(over="ignore"):
             l32, g32 = orc.critic_loss_and_grad(pb["critic"], xseq, label)
             l64, g64 = orc.critic_loss_and_grad(cr64, xseq.astype(np.float64), label.astype(np.float64))
-        gu.assert_parity("critic loss", ls.cpu().numpy() / (2 * B), l32, l64)
-        gu.assert_parity("critic grad", gs.cpu().numpy() / (2 * B), gu.pack_grads_critic(g32),
+        gu.assert_parity("critic loss", ls.cpu().numpy() / Bc, l32, l64)
+        gu.assert_parity("critic grad", gs.cpu().numpy() / Bc, gu.pack_grads_critic(g32),
                          gu.pack_grads_critic(g64))
     finally:
         eng.close()

@@ -108,3 +108,77 @@ def test_two_rank_allreduce_equals_single_process_batch_mean():
     assert (out[0][0], out[0][1], out[1][0], out[1][1]) == (0, 4, 4, 7)
     np.testing.assert_array_equal(out[0][2], out[1][2])       # replicas stay identical
     np.testing.assert_allclose(out[0][2], want, rtol=2e-5, atol=1e-7)   # N-GPU vs 1-GPU mean
+
+
+class _StubEngine:
+    pass
+
+
+class _StubPolicy:
+    """What sgd_pass touches of a policy: `_engine` (None until a loss call with samples builds one)."""
+
+    def __init__(self):
+        self._engine = None
+        self.built = 0
+
+    def to_device_params(self, params):
+        return params
+
+    def engine_for(self, batch, dparams=None):
+        self.built += 1
+        self._engine = _StubEngine()
+        return self._engine
+
+
+class _StubOpt:
+    def __init__(self):
+        self.engines = []
+
+    def update(self, engine, params, grads, opt_state):
+        self.engines.append(engine)
+        return params - 0.1 * grads, opt_state
+
+
+def _sgd_pass_worker(rank, world, port, out):
+    for p in (ROOT,):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from gan_mpc_amd import trainer_common as tc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        policy, opt = _StubPolicy(), _StubOpt()
+        data = torch.tensor([2.0, -4.0, 6.0])
+
+        def loss_and_grad(idx):
+            # like BaseMPC.loss_and_grad: an engine only when this rank has samples; the exchange always
+            packed = parallel.new_packed(2, "cpu", len(idx))
+            if len(idx) > 0:
+                policy.engine_for(len(idx))
+                packed[0] = data[idx].sum()
+                packed[1] = (2 * data[idx]).sum()
+            means = parallel.allreduce_mean_from_sums(packed)
+            return means[0], means[1:]
+
+        schedule = np.array([[0], [2], [1]])            # minibatches of ONE sample: rank 1's shard is always empty
+        params, _, mean_loss = tc.sgd_pass(policy, opt, {}, torch.zeros(1), schedule, loss_and_grad)
+        out[rank] = (policy.built, all(e is not None for e in opt.engines), len(opt.engines),
+                     float(params[0]), float(mean_loss))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sgd_pass_with_a_minibatch_smaller_than_the_world():
+    """batch_size < world_size: the rank that never receives a sample still takes every optimiser step (with an
+    engine) and stays a replica of the other one -- it used to hit `None.adam_clip_step` while rank 0 went on to
+    the next collective."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_sgd_pass_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in (0, 1):
+        built, all_engines, steps, p, loss = out[r]
+        assert all_engines and steps == 3 and built >= 1
+        np.testing.assert_allclose(p, -0.1 * 2 * (2.0 + 6.0 - 4.0), rtol=1e-6)
+        np.testing.assert_allclose(loss, (2.0 + 6.0 - 4.0) / 3, rtol=1e-6)
+    assert out[0][3] == out[1][3]
