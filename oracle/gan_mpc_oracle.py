@@ -538,6 +538,8 @@ def ilqr(dyn, cmlp, mpc_w, goal, x0, U, kwargs=None, trace=None):
     obj_step = np.full((B,), np.inf, dt)
     U_step = np.full((B,), np.inf, dt)
 
+    crit = {}
+
     def cont():
         with np.errstate(invalid="ignore", over="ignore"):
             gn = np.sqrt(np.sum(grad * grad, axis=(1, 2)))
@@ -550,12 +552,14 @@ def ilqr(dyn, cmlp, mpc_w, goal, x0, U, kwargs=None, trace=None):
         potential = (gn > kw["grad_norm_threshold"]) & (
             gn > kw["relative_grad_norm_threshold"] * aobj
         )
+        # (the criterion's quantities, for tests that leave out trajectories decided within rounding of a threshold)
+        crit.update(gn=gn.copy(), aobj=aobj.copy(), un=un.copy(), obj_step=obj_step.copy(), U_step=U_step.copy())
         return (it < kw["maxiter"]) & progressing & potential & (alpha > kw["alpha_min"])
 
     while True:
         act = cont()
         if trace is not None:
-            trace.append(dict(active=act.copy(), obj=obj.copy(), alpha=alpha.copy()))
+            trace.append(dict(active=act.copy(), obj=obj.copy(), alpha=alpha.copy(), crit=dict(crit)))
         if not act.any():
             break
         Q, q, R, r, M, A, Bm = lqr
