@@ -359,6 +359,9 @@ static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const
   int grid = (ntiles + 3) / 4;
   constexpr int occ = GMPC_REGS_OCC(NT, TAIL);
   if (grid > 256 * occ) grid = 256 * occ;   // persistent workgroups, occ per CU
+  // (measured, round 3: one workgroup per CU -- 256 of the 512 registers of every SIMD left to other kernels --
+  // costs 5.5 % alone (1.141 -> 1.204 ms), and the critic's kernels beside it are starved by its back-to-back
+  // 64-cycle MFMAs: k_head2 0.05 -> 0.37 ms, k_lstm_bwd2 0.11 -> 0.87 ms.  The chain keeps the chip to itself.)
   hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, WIDE>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
                      dyn, lp, masks, active, AB, ntiles, samp_mul, samp_add);
   snprintf(g_last_name, sizeof(g_last_name), "k_linearize_regs<%d, %d, %d, %s>", NT, KS, TAIL, WIDE ? "true" : "false");

@@ -528,7 +528,9 @@ static size_t ls16_lds(int nob, int T);
 bool gmpc_ls16_shape(const TrajArgs& a) {
   const char* e = getenv("GMPC_LS");        // read per call: the tests switch forms inside one process
   const bool off = e != nullptr && strcmp(e, "rw") == 0;
-  if (off || !gmpc_traj_rw_shape(a) || a.n + a.m > 24 || a.m > 8 || a.n > 32 ||
+  // (the 16-candidate form is built for three hidden layers of 200; the 128- and 64-wide register-weight
+  // rollouts keep k_traj_rw<true> for every round)
+  if (off || !gmpc_traj_rw_shape(a) || a.dyn.dims[1] != 200 || a.n + a.m > 24 || a.m > 8 || a.n > 32 ||
       ls16_lds(a.n > 16 ? 2 : 1, a.T) > LS16_LDS_MAX)
     return false;
   for (int l = 0; l <= a.cost.L; ++l)

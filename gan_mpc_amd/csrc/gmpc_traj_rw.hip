@@ -27,8 +27,15 @@
 //               slot i; bias, relu and one float4 store give the next layer's activations
 // ------------------------------------------------------------------------------------------------
 #define GMPC_RW_THREADS 256
-#define GMPC_RW_XK 64     // weight rows of the last hidden layer kept in LDS instead of registers
-#define GMPC_RW_KHP 204   // row stride of the transposed W_L copy ([n][KHP], KHP = H + 4)
+// weight rows of the last hidden layer kept in LDS instead of registers: two 200 x 200 layers are 400 registers,
+// which with the loop's working set do not fit 512; the 128- and 64-wide instantiations (round 3) hold everything
+__host__ __device__ constexpr int rw_xk(int KH, int NHL) { return KH * NHL > 320 ? 64 : 0; }
+// row stride of the transposed W_L copy ([n][KHP])
+__host__ __device__ constexpr int rw_khp(int KH) { return KH + 4; }
+// K range of the output layer taken by wave w: [rw_kb(KH, w), rw_kb(KH, w + 1)), multiples of 4
+__host__ __device__ constexpr int rw_kb(int KH, int w) {
+  return KH == 200 ? (w == 0 ? 0 : w == 1 ? 52 : w == 2 ? 104 : w == 3 ? 152 : 200) : (KH / 4) * w;
+}
 
 // weight rows of a layer that live in LDS: 8 q + {2, 3, 6, 7} for q < QX
 __host__ __device__ constexpr bool rw_row_in_lds(int k, int QX) { return (k >> 3) < QX && (k & 2) != 0; }
@@ -100,16 +107,16 @@ __device__ __forceinline__ f32x4_t rw_layer(const float* wr, const float4* hin, 
 }
 
 // output-layer partial of wave W: k in [K0, K1), B operand from the transposed LDS copy of W_L
-template <int K0, int K1>
+template <int K0, int K1, int KHP>
 __device__ __forceinline__ f32x4_t rw_out_part(const float4* hin, const float* wlT, int n) {
-  static_assert(K0 % 4 == 0 && K1 % 4 == 0, "float4 reads of the weight row");
+  static_assert(K0 % 4 == 0 && K1 % 4 == 0 && K1 > K0, "float4 reads of the weight row");
   const int lane = threadIdx.x & 63;
   const float* hf = reinterpret_cast<const float*>(hin);
   constexpr int R0 = K0 >> 4, R1 = (K1 - 1) >> 4;
   float ar[R1 - R0 + 1];
 #pragma unroll
   for (int r = R0; r <= R1; ++r) ar[r - R0] = hf[64 * r + lane];
-  const float4* wrow = reinterpret_cast<const float4*>(wlT + (size_t)(lane < n ? lane : n - 1) * GMPC_RW_KHP + K0);
+  const float4* wrow = reinterpret_cast<const float4*>(wlT + (size_t)(lane < n ? lane : n - 1) * KHP + K0);
   float4 wv[(K1 - K0) / 4];
 #pragma unroll
   for (int q = 0; q < (K1 - K0) / 4; ++q) wv[q] = wrow[q];
@@ -133,6 +140,8 @@ __device__ __forceinline__ f32x4_t rw_out_part(const float4* hin, const float* w
 // (trajectory, step size) item of the round's work list) instead of plain rollouts.
 template <bool LS, int KH, int NHL, int K0Q>
 __global__ __launch_bounds__(GMPC_RW_THREADS, 1) void k_traj_rw(TrajArgs a) {
+  static_assert(KH % 16 == 0 || KH == 200, "output-layer K split in multiples of 4");
+  constexpr int XK = rw_xk(KH, NHL), KHP = rw_khp(KH);
   // dynamic LDS: actA | actB (aw float4 each) | part (pw) | ksp (256, unused here) | xcur (32 rows: x, then
   // u, then zeros -- the layer-0 input) | transposed W_L [n][KHP] | LDS weight rows [XK / 4][256] float4
   extern __shared__ __attribute__((aligned(16))) char smem_traj[];
@@ -176,8 +185,8 @@ __global__ __launch_bounds__(GMPC_RW_THREADS, 1) void k_traj_rw(TrajArgs a) {
   const int Lh = a.dyn.L - 1;
   const size_t mstride = (size_t)T * Lh * GMPC_MW;   // mask words per trajectory
   // transposed copy of W_L, [n][KHP]: lane `no` of the output layer reads its weight row 4 k at a time
-  for (int e = tid; e < n * GMPC_RW_KHP; e += blockDim.x) {
-    const int no = e / GMPC_RW_KHP, k = e - no * GMPC_RW_KHP;
+  for (int e = tid; e < n * KHP; e += blockDim.x) {
+    const int no = e / KHP, k = e - no * KHP;
     wl_s[e] = k < KH ? a.dyn.W[Lh][(size_t)k * n + no] : 0.f;
   }
   const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]), w2 = sigmoidf_(a.mpc_w[2]);
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(GMPC_RW_THREADS, 1) void k_traj_rw(TrajArgs a) {
       constexpr int hl = decltype(hc)::value;
       const float* Wl = a.dyn.W[hl + 1];
       // rows 8 q + {2, 3, 6, 7} (q < XK / 4) of the last layer -> LDS, the others -> registers in row order
-      constexpr int qx = hl == NHL - 1 ? GMPC_RW_XK / 4 : 0;
+      constexpr int qx = hl == NHL - 1 ? XK / 4 : 0;
       rw_static_for<KH>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if constexpr (!rw_row_in_lds(k, qx)) {
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(GMPC_RW_THREADS, 1) void k_traj_rw(TrajArgs a) {
       });
       if constexpr (hl == NHL - 1) {
 #pragma unroll 4
-        for (int q = 0; q < GMPC_RW_XK / 4; ++q) {
+        for (int q = 0; q < XK / 4; ++q) {
           const float* wq = Wl + (size_t)(8 * q) * KH + nnA;
           wx_s[q * GMPC_RW_THREADS + tid] = nnA < KH ? make_float4(wq[2 * KH], wq[3 * KH], wq[6 * KH], wq[7 * KH])
                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(GMPC_RW_THREADS, 1) void k_traj_rw(TrajArgs a) {
     float4* hout = actB;
     rw_static_for<NHL>([&](auto hc) __attribute__((always_inline)) {
       constexpr int hl = decltype(hc)::value;
-      const f32x4_t d = rw_layer<KH, (hl == NHL - 1 ? GMPC_RW_XK : 0)>(wr[hl], hin, wx_s, rbias[hl + 1]);
+      const f32x4_t d = rw_layer<KH, (hl == NHL - 1 ? XK : 0)>(wr[hl], hin, wx_s, rbias[hl + 1]);
       rw_hidden_epilogue(d, nnA, KH, hout, mb + (hl + 1) * GMPC_MW, mstride, wbits);
       __syncthreads();
       TS_(3 + hl)
@@ -356,12 +365,11 @@ __global__ __launch_bounds__(GMPC_RW_THREADS, 1) void k_traj_rw(TrajArgs a) {
     });
     {
       // output layer: the K range is split over the 4 waves; lane = output coordinate
-      static_assert(KH == 200, "K split of the output layer");
       f32x4_t d;
-      if (wave == 0) d = rw_out_part<0, 52>(hin, wl_s, n);
-      else if (wave == 1) d = rw_out_part<52, 104>(hin, wl_s, n);
-      else if (wave == 2) d = rw_out_part<104, 152>(hin, wl_s, n);
-      else d = rw_out_part<152, 200>(hin, wl_s, n);
+      if (wave == 0) d = rw_out_part<rw_kb(KH, 0), rw_kb(KH, 1), KHP>(hin, wl_s, n);
+      else if (wave == 1) d = rw_out_part<rw_kb(KH, 1), rw_kb(KH, 2), KHP>(hin, wl_s, n);
+      else if (wave == 2) d = rw_out_part<rw_kb(KH, 2), rw_kb(KH, 3), KHP>(hin, wl_s, n);
+      else d = rw_out_part<rw_kb(KH, 3), rw_kb(KH, 4), KHP>(hin, wl_s, n);
       if (lane < 32) part[wave * 32 + lane] = make_float4(d[0], d[1], d[2], d[3]);
     }
     __syncthreads();
@@ -460,49 +468,60 @@ __global__ __launch_bounds__(GMPC_RW_THREADS, 1) void k_traj_rw(TrajArgs a) {
 }
 
 // ---- host side --------------------------------------------------------------------------------------
-// the shapes the register-weight form is instantiated for: three equal hidden layers of width 200, state
-// and control within one 32-row input block
+// the shapes the register-weight form is instantiated for: three equal hidden layers of width 200 (the reference's
+// default), 128 or 64, state and control within one 32-row input block
+static int rw_width(const TrajArgs& a) {
+  const int Lh = a.dyn.L - 1;
+  if (Lh != 3 || a.n > 32 || a.m > 32 || a.n + a.m > 32) return 0;
+  const int H = a.dyn.dims[1];
+  if (H != 200 && H != 128 && H != 64) return 0;
+  for (int l = 1; l <= Lh; ++l)
+    if (a.dyn.dims[l] != H) return 0;
+  return H;
+}
 bool gmpc_traj_rw_shape(const TrajArgs& a) {
   static const bool off = getenv("GMPC_TRAJ") != nullptr && strcmp(getenv("GMPC_TRAJ"), "valu") == 0;
-  const int Lh = a.dyn.L - 1;
-  if (off || Lh != 3 || a.n > 32 || a.m > 32 || a.n + a.m > 32) return false;
-  for (int l = 1; l <= Lh; ++l)
-    if (a.dyn.dims[l] != 200) return false;
-  return true;
+  return !off && rw_width(a) != 0;
 }
 
 // LDS of one workgroup; sets the sizing fields of `a` (aw is set by the caller: widest layer of both networks)
 size_t gmpc_traj_rw_lds(TrajArgs& a) {
+  const int H = rw_width(a);
   a.pw = GMPC_RW_THREADS;
   a.sw0 = 0;                                             // W_0 lives in registers
-  a.swl = a.n * GMPC_RW_KHP;                             // transposed W_L
+  a.swl = a.n * rw_khp(H);                               // transposed W_L
   return ((size_t)2 * a.aw + a.pw + GMPC_THREADS + 32) * sizeof(float4) +
-         ((size_t)a.swl + (size_t)GMPC_RW_XK * GMPC_RW_THREADS) * sizeof(float);
+         ((size_t)a.swl + (size_t)rw_xk(H, 2) * GMPC_RW_THREADS) * sizeof(float);
 }
 
 // one workgroup per 4 trajectories (ls = false) / work-list items (ls = true: `grid` covers the largest
 // possible work list, the kernel reads the actual count)
-void gmpc_launch_traj_rw(const TrajArgs& a, bool ls, int grid, size_t lds, hipStream_t s) {
+template <int KH, int K0Q>
+static void launch_rw(const TrajArgs& a, bool ls, int grid, size_t lds, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
     // one workgroup per CU (the registers hold the weights): up to 160 KB of LDS
-    const void* ks[] = {reinterpret_cast<const void*>(&k_traj_rw<false, 200, 2, 6>),
-                        reinterpret_cast<const void*>(&k_traj_rw<false, 200, 2, 8>),
-                        reinterpret_cast<const void*>(&k_traj_rw<true, 200, 2, 6>),
-                        reinterpret_cast<const void*>(&k_traj_rw<true, 200, 2, 8>)};
+    const void* ks[] = {reinterpret_cast<const void*>(&k_traj_rw<false, KH, 2, K0Q>),
+                        reinterpret_cast<const void*>(&k_traj_rw<true, KH, 2, K0Q>)};
     for (const void* k : ks) {
       (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
       (void)hipGetLastError();
     }
     attr = true;
   }
+  if (!ls) hipLaunchKernelGGL((k_traj_rw<false, KH, 2, K0Q>), dim3(grid), dim3(GMPC_RW_THREADS), lds, s, a);
+  else hipLaunchKernelGGL((k_traj_rw<true, KH, 2, K0Q>), dim3(grid), dim3(GMPC_RW_THREADS), lds, s, a);
+}
+
+void gmpc_launch_traj_rw(const TrajArgs& a, bool ls, int grid, size_t lds, hipStream_t s) {
   const bool small = a.n + a.m <= 24;
-  if (!ls && small)
-    hipLaunchKernelGGL((k_traj_rw<false, 200, 2, 6>), dim3(grid), dim3(GMPC_RW_THREADS), lds, s, a);
-  else if (!ls)
-    hipLaunchKernelGGL((k_traj_rw<false, 200, 2, 8>), dim3(grid), dim3(GMPC_RW_THREADS), lds, s, a);
-  else if (small)
-    hipLaunchKernelGGL((k_traj_rw<true, 200, 2, 6>), dim3(grid), dim3(GMPC_RW_THREADS), lds, s, a);
-  else
-    hipLaunchKernelGGL((k_traj_rw<true, 200, 2, 8>), dim3(grid), dim3(GMPC_RW_THREADS), lds, s, a);
+  switch (rw_width(a)) {
+    case 200:
+      if (small) launch_rw<200, 6>(a, ls, grid, lds, s);
+      else launch_rw<200, 8>(a, ls, grid, lds, s);
+      break;
+    case 128: launch_rw<128, 8>(a, ls, grid, lds, s); break;       // (one layer-0 form: 32 input rows)
+    case 64: launch_rw<64, 8>(a, ls, grid, lds, s); break;
+    default: break;
+  }
 }

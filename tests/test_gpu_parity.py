@@ -25,6 +25,10 @@ SHAPES = {
     "rw-wide-io": (22, 9, 70, 6, dict(out_scale=0.3)),
     "rw-ragged": (17, 6, 9, 7, {}),
     "rw-one-step": (17, 6, 1, 6, {}),          # horizon 1: the first step is the last one
+    # the 128- and 64-wide instantiations of the register-weight rollout / line search (round 3; the Jacobian chain
+    # has its regs<4, 64> / regs<2, 32> forms for them): waves 2-3 / 1-3 of the workgroup hold no neuron
+    "rw-128": (9, 3, 12, 10, dict(dyn_hidden=(128, 128, 128), cost_hidden=(32,), cost_fout=4, out_scale=0.3)),
+    "rw-64": (6, 2, 9, 7, dict(dyn_hidden=(64, 64, 64), cost_hidden=(16,), cost_fout=3, out_scale=0.3)),
     # the 16-candidate form of the line search (gmpc_ls16.hip; the tests force it with GMPC_LS16_SPLIT=1): a
     # last workgroup with unused candidates, the three instantiations (layer-0 k-steps 4 / 6, one or two row
     # blocks of the output layer)
@@ -210,6 +214,7 @@ def test_adam_clip_step():
 
 
 @pytest.mark.parametrize("name", ["tiny-ragged", "trained-like", "big-70", "rw-wide-io", "rw-ragged", "rw-one-step",
+                                  "rw-128", "rw-64",
                                   "dynl-small", "dynl-two-layers", "dynl-big", "lowrank-2h"])
 def test_ilqr_single_iteration_teacher_forced(name):
     """maxiter=1 from the same start: tvlqr + line search + re-linearisation, one iteration."""
