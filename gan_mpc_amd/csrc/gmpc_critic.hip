@@ -943,14 +943,18 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_WG_OCC) void k_wgrad_batch(WgBat
   } else {
     wgrad_tile_x4<GMPC_WG_RING, NTW>(bp0, q.ldb, Kp, afn, acc);
   }
+  // tiles 4 j .. 4 j + 3 of a lane are four consecutive columns: one 16-byte store per accumulator row (N % 128 == 0
+  // and the partial buffer's slices are multiples of 4 floats, so the address is aligned)
   float* cp = part + q.part_off + (size_t)chunk * M * N;
 #pragma unroll
-  for (int nt = 0; nt < NTW; ++nt) {
-    const int col = ng * 32 * NTW + (nt >> 2) * 128 + 4 * l31 + (nt & 3);
+  for (int j = 0; j < NTW / 4; ++j) {
+    const int col = ng * 32 * NTW + j * 128 + 4 * l31;
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) {
       const int row = mi * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
-      if (row < M) cp[(size_t)row * N + col] = acc[nt][rg];
+      if (row < M)
+        *reinterpret_cast<float4*>(cp + (size_t)row * N + col) =
+            make_float4(acc[4 * j][rg], acc[4 * j + 1][rg], acc[4 * j + 2][rg], acc[4 * j + 3][rg]);
     }
   }
 }
@@ -1057,6 +1061,7 @@ bool gmpc_launch_wgrad_batch(WgProb* probs, int np, float* part, long part_float
     } else {
       q.cchunks = 0; q.crpc = 0; q.cs_block0 = cs_blocks; q.cs_part_off = off;
     }
+    off = (off + 3) & ~3L;               // every slice starts on a 16-byte boundary (float4 stores of the partials)
     q.red_block0 = red_blocks;
     red_blocks += (q.M * q.N + 63) / 64;
     q.cs_red_block0 = red_blocks;

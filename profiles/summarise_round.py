@@ -10,6 +10,8 @@ import sys
 v = sys.argv[1]
 rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 src = f"gpurun_out/prof_{v}" if rnd == "r01" else f"gpurun_out/prof_{rnd}{v}"
+if not __import__("os").path.isdir(src):           # profile_round.sh r03_v1 -> gpurun_out/prof_r03_v1
+    src = f"gpurun_out/prof_{rnd}_{v}"
 shutil.copy(f"{src}/bench.json", f"profiles/{rnd}_{v}_bench.json")
 shutil.copy(f"{src}/kernel_stats.csv", f"profiles/{rnd}_{v}_bench_kernel_stats.csv")
 shutil.copy(f"{src}/bench_under_rocprof.json", f"profiles/{rnd}_{v}_bench_under_rocprof.json")
