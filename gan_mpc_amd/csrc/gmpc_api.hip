@@ -49,8 +49,6 @@ size_t gmpc_riccati_lds_bytes(int n, int m);
 void gmpc_launch_transpose(int, int, const float*, float*, hipStream_t);
 void gmpc_launch_lstm_fwd(int, const CriticDesc&, const float*, float*, float*, float*, float*,
                           const float*, hipStream_t);
-void gmpc_launch_head(int, const CriticDesc&, int, const float*, const float*, float*, float*,
-                      float*, float*, float*, int, hipStream_t);
 void gmpc_launch_lstm_bwd(int, const CriticDesc&, const float*, const float*, const float*, float*,
                           float*, hipStream_t);
 void gmpc_launch_wgrad(int, int, int, const float*, int, const float*, int, float*, float*, int,

@@ -1,5 +1,7 @@
 // Critic (discriminator) kernels: LSTM(F) over the T+1 rows of each sequence, final h -> relu head ->
-// score; BCE / generator loss; BPTT; weight gradients as row-sum GEMMs; clip + Adam.
+// score; BCE / generator loss; BPTT; weight gradients as row-sum GEMMs; clip + Adam.  First generation of the LSTM
+// kernels (any input width; the n <= 32 shapes run gmpc_critic_lstm.hip since round 3), the weight-gradient GEMMs,
+// the optimiser kernels.
 //
 // Reference arithmetic: critic/nn.py:28-42 (flax OptimizedLSTMCell scanned over the sequence, zero
 // carry, gate order i,f,g,o), gan/js_policy.py:41-68 (losses), gan/runner.py:51-63 (optimiser).
@@ -147,130 +149,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd(int Bc, CriticDesc cd
   }
 }
 
-// Head forward + loss + head backward, per sequence.  loss_kind 0: BCE with labels (js_policy.py:
-// 41-46) -> dscore = -(1-p) or p; 1: generator loss (js_policy.py:60-68) -> dscore = -1;
-// 2: score only, dscore = +1 (plain VJP of the score).  Stores per-layer inputs `acts` and deltas
-// `dels` for the weight-gradient GEMMs, dhT for the BPTT, score and per-sequence loss.
-template <int R4>
-__global__ __launch_bounds__(GMPC_THREADS) void k_head(int Bc, CriticDesc cd, int loss_kind,
-                                                       const float* hT, const float* label,
-                                                       float* score, float* loss, float* acts,
-                                                       float* dels, float* dhT, int act_stride) {
-  constexpr int SB = 4 * R4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4* bufA = reinterpret_cast<float4*>(smem);
-  float4* bufB = bufA + GMPC_THREADS * R4;
-  float4* part = bufB + GMPC_THREADS * R4;
-  float* zpos = reinterpret_cast<float*>(part + GMPC_THREADS * R4);  // [L][256][SB]
-  const int tid = threadIdx.x;
-  const int s0 = blockIdx.x * SB;
-  const MlpDesc& hd = cd.head;
-  const int L = hd.L, F = cd.F;
-  float* af = reinterpret_cast<float*>(bufA);
-  for (int e = tid; e < F * SB; e += blockDim.x) {
-    const int sb = e / F, k = e - sb * F;
-    const int s = min(s0 + sb, Bc - 1);
-    const float v = hT[(size_t)s * F + k];
-    af[k * SB + sb] = v;
-    if (s0 + sb < Bc) acts[(size_t)(s0 + sb) * act_stride + k] = v;
-  }
-  __syncthreads();
-  float4* in = bufA;
-  float4* out = bufB;
-  int aoff = F;
-  for (int l = 0; l < L - 1; ++l) {
-    const int K = hd.dims[l], N = hd.dims[l + 1];
-    const float bj = tid < N ? hd.b[l][tid] : 0.f;
-    float4 acc[R4];
-#pragma unroll
-    for (int q = 0; q < R4; ++q) acc[q] = make_float4(bj, bj, bj, bj);
-    dense_rows<R4>(hd.W[l], K, N, tid, in, acc);
-    if (tid < N) {
-#pragma unroll
-      for (int q = 0; q < R4; ++q) {
-        float4 v = acc[q];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-          const int sb = q * 4 + cc;
-          const float z = f4get(v, cc);
-          zpos[(l * GMPC_THREADS + tid) * SB + sb] = z > 0.f ? 1.f : 0.f;
-          const float r = fmaxf(z, 0.f);
-          f4set(v, cc, r);
-          if (s0 + sb < Bc) acts[(size_t)(s0 + sb) * act_stride + aoff + tid] = r;
-        }
-        out[tid * R4 + q] = v;
-      }
-    }
-    aoff += N;
-    __syncthreads();
-    float4* tmp = in; in = out; out = tmp;
-  }
-  // last layer: one output
-  dense_small<R4>(hd.W[L - 1], hd.dims[L - 1], 1, in, part);
-  // loss and dscore (thread sb)
-  float* dsc = reinterpret_cast<float*>(out);   // [1][SB] delta of the last layer
-  if (tid < SB) {
-    const int sb = tid;
-    const float sc = reinterpret_cast<float*>(part)[sb] + hd.b[L - 1][0];
-    float ds, ls;
-    if (loss_kind == 0) {
-      const float p = sigmoidf_(sc);
-      const int s = min(s0 + sb, Bc - 1);
-      const bool pos = label[s] > 0.f;
-      ls = -logf(pos ? p : 1.f - p);
-      ds = pos ? -(1.f - p) : p;
-    } else if (loss_kind == 1) {
-      const float p = sigmoidf_(sc);
-      ls = -logf(p) + logf(1.f - p);
-      ds = -1.f;
-    } else {
-      ls = 0.f;
-      ds = 1.f;
-    }
-    dsc[sb] = ds;
-    if (s0 + sb < Bc) {
-      score[s0 + sb] = sc;
-      loss[s0 + sb] = ls;
-    }
-  }
-  __syncthreads();
-  // backward through the head; `out` holds delta of layer l as [N_l][SB]
-  int doff = 0;
-  for (int l = 0; l < L; ++l) doff += hd.dims[l + 1];
-  for (int l = L - 1; l >= 0; --l) {
-    const int K = hd.dims[l + 1], N = hd.dims[l];
-    doff -= K;
-    const float* df = reinterpret_cast<const float*>(out);
-    for (int e = tid; e < K * SB; e += blockDim.x) {
-      const int j = e / SB, sb = e - j * SB;
-      if (s0 + sb < Bc) dels[(size_t)(s0 + sb) * act_stride + doff + j] = df[j * SB + sb];
-    }
-    float4 acc[R4];
-#pragma unroll
-    for (int q = 0; q < R4; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    dense_rows<R4>(hd.WT[l], K, N, tid, out, acc);
-    __syncthreads();
-    if (tid < N) {
-#pragma unroll
-      for (int q = 0; q < R4; ++q) {
-        float4 v = acc[q];
-        if (l > 0) {
-#pragma unroll
-          for (int cc = 0; cc < 4; ++cc)
-            f4set(v, cc, f4get(v, cc) * zpos[((l - 1) * GMPC_THREADS + tid) * SB + q * 4 + cc]);
-        }
-        in[tid * R4 + q] = v;
-      }
-    }
-    __syncthreads();
-    float4* tmp = in; in = out; out = tmp;
-  }
-  const float* df = reinterpret_cast<const float*>(out);   // d hT as [F][SB]
-  for (int e = tid; e < F * SB; e += blockDim.x) {
-    const int sb = e / F, k = e - sb * F;
-    if (s0 + sb < Bc) dhT[(size_t)(s0 + sb) * F + k] = df[k * SB + sb];
-  }
-}
+// (The head -- forward, loss, backward -- is k_head2 in gmpc_critic_lstm.hip for every shape since round 3.)
 
 template <int R4, int NXR>
 __global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd(int Bc, CriticDesc cd, const float* gates,
@@ -632,17 +511,6 @@ void gmpc_launch_lstm_fwd(int Bc, const CriticDesc& cd, const float* xseq, float
   else
     hipLaunchKernelGGL((k_lstm_fwd<R4, 0>), dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, xseq, gates,
                        cs, hp, hT, stage_w, xproj);
-}
-
-void gmpc_launch_head(int Bc, const CriticDesc& cd, int loss_kind, const float* hT,
-                      const float* label, float* score, float* loss, float* acts, float* dels,
-                      float* dhT, int act_stride, hipStream_t s) {
-  constexpr int R4 = GMPC_CR4;
-  const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
-  const size_t lds = 3 * (size_t)GMPC_THREADS * R4 * sizeof(float4) +
-                     (size_t)GMPC_MAX_LAYERS * GMPC_THREADS * 4 * R4 * sizeof(float);
-  hipLaunchKernelGGL(k_head<R4>, dim3(grid), dim3(GMPC_THREADS), lds, s, Bc, cd, loss_kind, hT, label,
-                     score, loss, acts, dels, dhT, act_stride);
 }
 
 void gmpc_launch_lstm_bwd(int Bc, const CriticDesc& cd, const float* gates, const float* cs,
