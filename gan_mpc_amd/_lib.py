@@ -90,6 +90,7 @@ SIGNATURES = {
     "gmpc_bgemm_tn": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, C.c_float, C.c_float,
                                 _P]),
     "gmpc_linesearch_candidates": (C.c_long, [_P]),
+    "gmpc_linesearch_stats": (C.c_int, [_P, C.POINTER(C.c_long), C.c_int]),
     "gmpc_profile_enable": (C.c_int, [_P, C.c_int]),
     "gmpc_set_linearize_event": (C.c_int, [_P, _P]),
     "gmpc_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]),

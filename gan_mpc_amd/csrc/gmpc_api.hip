@@ -339,7 +339,7 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
   if (!rc) rc = dalloc(c, &c->lsw.cnt, B);
   if (!rc) rc = dalloc(c, &c->lsw.kfirst, B);
   if (!rc) rc = dalloc(c, &c->lsw.prevk, B);
-  if (!rc) rc = dalloc(c, &c->lsw.counts, GMPC_LS_ROUNDS_MAX + 1);
+  if (!rc) rc = dalloc(c, &c->lsw.counts, GMPC_LS_ROUNDS_MAX + 1 + GMPC_LS_STATS);
   if (!rc) rc = dalloc(c, &c->lsw.run, B);
   if (!rc) rc = dalloc(c, &c->lsw.objc, GMPC_LS_ITEMS * B);
   c->big = s.n > 64;
@@ -745,7 +745,7 @@ extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float*
   ls.alpha_0 = opts->alpha_0; ls.alpha_min = opts->alpha_min;
   // a fresh solve starts its first line search with a single full step per trajectory
   HIP_TRY(hipMemsetAsync(c->lsw.prevk, 0, B * sizeof(int), s));
-  HIP_TRY(hipMemsetAsync(c->lsw.counts + GMPC_LS_ROUNDS_MAX, 0, sizeof(int), s));
+  HIP_TRY(hipMemsetAsync(c->lsw.counts + GMPC_LS_ROUNDS_MAX, 0, (1 + GMPC_LS_STATS) * sizeof(int), s));
   // "Has every trajectory stopped?" is answered without stalling the queue: the continuation flags of
   // iteration `it` are copied to a pinned ring slot when the iteration is enqueued and looked at
   // GMPC_POLL_DEPTH iterations later, so the host runs at most that many iterations ahead of what it
@@ -1394,6 +1394,15 @@ extern "C" long gmpc_linesearch_candidates(gmpc_ctx* c) {
       hipMemcpy(&v, c->lsw.counts + GMPC_LS_ROUNDS_MAX, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
   return v;
+}
+
+extern "C" int gmpc_linesearch_stats(gmpc_ctx* c, long* out, int n) {
+  if (!c || !out) return fail(GMPC_EINVAL, "ctx / out is null");
+  int v[GMPC_LS_STATS];
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpy(v, c->lsw.counts + GMPC_LS_ROUNDS_MAX + 1, sizeof(v), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; ++i) out[i] = i < GMPC_LS_STATS ? v[i] : 0;
+  return 0;
 }
 
 extern "C" int gmpc_set_linearize_event(gmpc_ctx* c, void* ev) {

@@ -206,11 +206,14 @@ struct LsWork {
                                        // kfirst .. kfirst+cnt-1; candidate j is item slot[b*8 + j]
   int* slot;                           // [maxB * GMPC_LS_ITEMS]
   int* prevk;                       // [maxB] halving count accepted by the previous line search
-  int* counts;                      // [GMPC_LS_ROUNDS_MAX + 1] items per round
+  int* counts;                      // [GMPC_LS_ROUNDS_MAX + 1] items per round, then GMPC_LS_STATS counters
+                                    // since the solve began (gmpc_linesearch_stats): [0..15] line searches
+                                    // that accepted halving k, [16] exhausted ones, [24 + r] items of round r
   int* run;                         // [maxB]
   float* objc;                      // [maxB * GMPC_LS_ITEMS]
 };
 #define GMPC_LS_ROUNDS_MAX 40
+#define GMPC_LS_STATS 64
 
 struct RiccatiArgs {
   int B, n, m, T, mode;

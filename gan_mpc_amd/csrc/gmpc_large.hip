@@ -92,6 +92,139 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bgemm_tn(BgemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Streaming form of the thin products (k_bthin<WIDE_X>): one operand has at most 32 columns per strip, the
+// other one is wide and comes from HBM exactly once per strip (PB = P B and [H | G_r] = B^T [PA | PB] of the
+// large-state pass: 290 / 302 MB per time step at the C4 shard).  k_bgemm_tn reads the wide operand one dword
+// per lane and k-step with two k-steps in flight: ~1 KB per wave on its way at a time, 1.1-1.7 TB/s.  Here a
+// wave owns 128 consecutive columns of the wide operand as FOUR interleaved MFMA tiles -- tile j = columns
+// 128 g + 4 i + j, i = 0..31 -- so a lane's 16-byte load of row 2 ks + half IS the operand of the four tiles
+// (the matrix instruction does not care which column sits in which tile row as long as the epilogue knows),
+// and BT_RD k-steps are in flight (BT_RD KB per wave; 6 or 10 measure the same).  The rows need not be 16-byte aligned (n + m = 393 at
+// C4): the loads carry 4-byte alignment, which the memory pipeline of gfx950 serves in its unaligned mode.
+// The wide operand is read up to 127 columns past its width in its last column group (clamped to the row's
+// last 16 bytes: never out of the matrix), rows past K are not read (clamped, the thin operand is zero there).
+// ------------------------------------------------------------------------------------------------
+#define BT_RD 10
+struct __attribute__((packed, aligned(4))) bt_f4 { float x, y, z, w; };
+struct __attribute__((packed, aligned(4))) bt_f2 { float x, y; };
+
+// NTJ = 2: 64 columns per wave, 8-byte loads (twice the waves: fills the chip when batch * width / 128 does not)
+template <bool WIDE_X, int NTJ, int RD>
+__global__ __launch_bounds__(GMPC_THREADS) void k_bthin(BgemmArgs a) {
+  constexpr int GW = 32 * NTJ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int Wd = WIDE_X ? a.M : a.N, Th = WIDE_X ? a.N : a.M;       // wide / thin extents
+  const int groups = (Wd + GW - 1) / GW, strips = (Th + 31) >> 5;
+  const long total = (long)a.batch * groups * strips;
+  const long item = (long)blockIdx.x * (GMPC_THREADS / 64) + wave;
+  if (item >= total) return;
+  const int b = (int)(item / (groups * strips));
+  const int rem = (int)(item - (long)b * groups * strips);
+  const int g = rem / strips, st = rem - g * strips;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  const float* Wp = (WIDE_X ? a.X + (size_t)b * a.sx : a.Y + (size_t)b * a.sy);
+  const float* Tp = (WIDE_X ? a.Y + (size_t)b * a.sy : a.X + (size_t)b * a.sx);
+  const int ldw = WIDE_X ? a.ldx : a.ldy, ldt = WIDE_X ? a.ldy : a.ldx;
+  const int K = a.K;
+  // this lane's 4 wide columns and its thin column
+  const int wc = GW * g + NTJ * l31;
+  // lanes past the width read the row's last 16 bytes instead (never out of the matrix); when the width is not
+  // a multiple of 4 one lane straddles the edge and finds its columns `sh` places further up in that load
+  const int wcl = min(wc, max(Wd - NTJ, 0));
+  const int sh = wc - wcl;
+  const bool ragged = (Wd & (NTJ - 1)) != 0;        // (uniform)
+  const int tc = 32 * st + l31;
+  const bool tok = tc < Th;
+  const float* wrow = Wp + wcl;
+  const float* trow = Tp + (tok ? tc : 0);
+  f32x16 acc[NTJ];
+#pragma unroll
+  for (int j = 0; j < NTJ; ++j)
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) acc[j][rg] = 0.f;
+  bt_f4 wq[RD];
+  float tq[RD];
+  const int KS = (K + 1) >> 1;
+  auto issue = [&](int ks, bt_f4& wv, float& tv) {
+    const int r = min(2 * ks + half, K - 1);
+    if (NTJ == 4) {
+      wv = *reinterpret_cast<const bt_f4*>(wrow + (size_t)r * ldw);
+    } else {
+      const bt_f2 q = *reinterpret_cast<const bt_f2*>(wrow + (size_t)r * ldw);
+      wv.x = q.x; wv.y = q.y;
+    }
+    tv = trow[(size_t)r * ldt];
+  };
+  auto mult = [&](int ks, bt_f4 wv, float tv) {
+    const float t = (tok && 2 * ks + half < K) ? tv : 0.f;
+    if (ragged) {
+      const bt_f4 q = wv;
+      if (NTJ == 4) {
+        wv.x = sh == 0 ? q.x : sh == 1 ? q.y : sh == 2 ? q.z : q.w;
+        wv.y = sh == 0 ? q.y : sh == 1 ? q.z : q.w;
+        wv.z = sh == 0 ? q.z : q.w;
+      } else {
+        wv.x = sh == 0 ? q.x : q.y;
+      }
+    }
+    const float wj[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+      acc[j] = WIDE_X ? __builtin_amdgcn_mfma_f32_32x32x2f32(wj[j], t, acc[j], 0, 0, 0)
+                      : __builtin_amdgcn_mfma_f32_32x32x2f32(t, wj[j], acc[j], 0, 0, 0);
+  };
+#pragma unroll
+  for (int i = 0; i < RD; ++i) issue(min(i, KS - 1), wq[i], tq[i]);
+  int ks = 0;
+  for (; ks + RD <= KS; ks += RD) {
+#pragma unroll
+    for (int i = 0; i < RD; ++i) {
+      const bt_f4 wv = wq[i];
+      const float tv = tq[i];
+      issue(min(ks + RD + i, KS - 1), wq[i], tq[i]);      // (past the end: the last k-step again, not used)
+      __builtin_amdgcn_sched_barrier(0);
+      mult(ks + i, wv, tv);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RD; ++i)
+    if (ks + i < KS) mult(ks + i, wq[i], tq[i]);
+  // epilogue: accumulator row i of tile j <-> wide column GW g + NTJ i + j (WIDE_X: a row of C), column l31 <->
+  // thin column (WIDE_X) / wide columns GW g + NTJ l31 + j (a run of NTJ floats of row i of C otherwise)
+#pragma unroll
+  for (int rg = 0; rg < 16; ++rg) {
+    const int i = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+    if (WIDE_X) {
+#pragma unroll
+      for (int j = 0; j < NTJ; ++j) {
+        const int row = GW * g + NTJ * i + j;
+        if (row < a.M && tok) {
+          float* cp = a.C + (size_t)b * a.sc + (size_t)row * a.ldc + tc;
+          float v = a.alpha * acc[j][rg];
+          if (a.beta != 0.f) v = fmaf(a.beta, *cp, v);
+          *cp = v;
+        }
+      }
+    } else {
+      const int row = 32 * st + i;
+      if (row < a.M) {
+        float* cp = a.C + (size_t)b * a.sc + (size_t)row * a.ldc + wc;
+#pragma unroll
+        for (int j = 0; j < NTJ; ++j) {
+          if (wc + j < a.N) {
+            float v = a.alpha * acc[j][rg];
+            if (a.beta != 0.f) v = fmaf(a.beta, cp[j], v);
+            cp[j] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // LDS-tiled variant for products whose M and N are both large: a workgroup of 4 waves (2 x 2) owns a
 // (64*WMT) x (64*WNT) block of C[b]; KC rows of X and Y at a time are staged through LDS (double
 // buffered, zero-filled past the matrix edges, so nothing is read out of bounds and a NaN in a
@@ -364,6 +497,27 @@ void gmpc_launch_bgemm_tn(const BgemmArgs& a, hipStream_t s) {
       default: launch_lds<2, 4>(a, s); break;
     }
     return;
+  }
+  // a thin product whose wide operand is worth streaming (k_bthin)
+  {
+    static const bool off = [] { const char* e = getenv("GMPC_BTHIN"); return e != nullptr && e[0] == '0'; }();
+    const bool widex = a.N <= 64 && a.M >= 128, widey = a.M <= 64 && a.N >= 128;
+    if (!off && (widex || widey) && a.K >= 2 * BT_RD) {
+      const int Wd = widex ? a.M : a.N, Th = widex ? a.N : a.M;
+      // 128 columns per wave (16-byte loads) when that still gives every SIMD a few waves, else 64 (8-byte loads,
+      // twice the waves: PB at the C4 shard is 1536 waves of 128 columns -- 1.5 per SIMD, 0.084 ms -- or 3072 of
+      // 64, 0.073 ms)
+      static const int ntj_env = [] { const char* e = getenv("GMPC_BTHIN_NTJ"); return e ? atoi(e) : 0; }();
+      const long waves4 = (long)a.batch * ((Wd + 127) / 128) * ((Th + 31) / 32);
+      const int ntj = ntj_env == 2 || ntj_env == 4 ? ntj_env : waves4 < 4096 ? 2 : 4;
+      const long total = (long)a.batch * ((Wd + 32 * ntj - 1) / (32 * ntj)) * ((Th + 31) / 32);
+      const dim3 grid((unsigned)((total + 3) / 4)), blk(GMPC_THREADS);
+#define BT_LAUNCH(WX, NJ) hipLaunchKernelGGL((k_bthin<WX, NJ, BT_RD>), grid, blk, 0, s, a)
+      if (widex) { if (ntj == 2) BT_LAUNCH(true, 2); else BT_LAUNCH(true, 4); }
+      else       { if (ntj == 2) BT_LAUNCH(false, 2); else BT_LAUNCH(false, 4); }
+#undef BT_LAUNCH
+      return;
+    }
   }
   // a thin product: one wave per strip (the second K-segment is not supported here)
   const int tiles = (a.N + 31) / 32;

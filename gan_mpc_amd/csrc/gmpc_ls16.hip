@@ -75,6 +75,17 @@ __device__ __forceinline__ float2 ls16_tail(const float* p12, const float* bias1
   return make_float2(fmaxf(s0, 0.f), fmaxf(s1, 0.f));
 }
 
+#ifdef GMPC_LS_ABORT_STATS
+// experiment: how early could a rejected candidate have been dropped (costs are >= 0, so a candidate whose running
+// cost has reached the objective to beat is rejected)?  [0] candidates, [1] sum of T, [2] sum over candidates of
+// the first step whose running cost reaches the objective (T + 1: never), [3] the same with the workgroup's
+// maximum for each of its candidates
+__device__ unsigned long long g_ls_abort_stats[4];
+extern "C" int gmpc_debug_abort_stats(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ls_abort_stats), sizeof(g_ls_abort_stats));
+}
+#endif
+
 // K0S: k-steps of layer 0 (n + m <= 4 K0S); NOB: 16-row blocks of the output layer (n <= 16 NOB)
 template <int K0S, int NOB>
 __global__ __launch_bounds__(LS16_THREADS, 1) void k_ls16(TrajArgs a) {
@@ -456,6 +467,23 @@ __global__ __launch_bounds__(LS16_THREADS, 1) void k_ls16(TrajArgs a) {
       float acc = 0.f;
       for (int t = 0; t < T; ++t) acc += cst[tid * T + t];
       s_obj[tid] = acc;
+#ifdef GMPC_LS_ABORT_STATS
+      {
+        const float oo = a.obj[BI(tid)];
+        float run = 0.f;
+        int tx = T + 1;
+        for (int t = 0; t < T; ++t) { run += cst[tid * T + t]; if (run >= oo && tx > T) tx = t + 1; }
+        if (!INB(tid)) tx = 0;
+        int mx = tx;
+        for (int o = 8; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+        if (INB(tid)) {
+          atomicAdd(&g_ls_abort_stats[0], 1ull);
+          atomicAdd(&g_ls_abort_stats[1], (unsigned long long)T);
+          atomicAdd(&g_ls_abort_stats[2], (unsigned long long)min(tx, T));
+          atomicAdd(&g_ls_abort_stats[3], (unsigned long long)min(mx, T));
+        }
+      }
+#endif
     }
   }
   // ---- terminal cost w2 |cost_mlp(x_T)|^2 on the matrix pipe as well: activations [k][16] in actA / actB,

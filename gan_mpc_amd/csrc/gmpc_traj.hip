@@ -311,7 +311,8 @@ __global__ void k_ls_init(int B, const int* active, float alpha_0, float alpha_m
 // steps), and a workgroup whose four candidates are all dead stops -- which only happens when
 // candidates of similar fate sit together.  One workgroup; cnt[b] candidates for trajectory b.
 __global__ __launch_bounds__(1024) void k_ls_place(int B, const int* cnt, const int* kfirst, int* item_b,
-                                                   int* item_k, int* slot, int* count, int* total) {
+                                                   int* item_k, int* slot, int* count, int* total,
+                                                   int* round_total) {
   __shared__ int s_n[GMPC_LS_ITEMS], s_base[GMPC_LS_ITEMS], s_fill[GMPC_LS_ITEMS];
   const int tid = threadIdx.x;
   if (tid < GMPC_LS_ITEMS) { s_n[tid] = 0; s_fill[tid] = 0; }
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(1024) void k_ls_place(int B, const int* cnt, const 
     for (int j = 0; j < GMPC_LS_ITEMS; ++j) { s_base[j] = acc; acc += s_n[j]; }
     *count = acc;
     *total += acc;          // candidate rollouts since the solve began (one workgroup: no race)
+    *round_total += acc;
   }
   __syncthreads();
   for (int b = tid; b < B; b += blockDim.x) {
@@ -346,6 +348,7 @@ struct LsDecideArgs {
   const float* objc; const float* Xc; const float* Uc; const uint32_t* maskc;
   float* X; float* U; uint32_t* masks;
   float* obj; float* obj_step; float* U_step; float* alpha;
+  int* stats;            // LsWork::counts + GMPC_LS_ROUNDS_MAX + 1
 };
 
 __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
       a.prevk[b] = k0 + acc;
       a.run[b] = 0;
       a.cnt[b] = 0;
+      atomicAdd(a.stats + min(k0 + acc, 15), 1);
     } else if (k0 + R >= a.k_max) {      // every step size down to alpha_min failed
       a.alpha[b] = halved(a.k_max);
       a.U_step[b] = 0.f;
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
       a.prevk[b] = a.k_max - 1;
       a.run[b] = 0;
       a.cnt[b] = 0;
+      atomicAdd(a.stats + 16, 1);
     } else {                               // queue the next GMPC_LS_NEXT halvings (k_ls_place)
       const int left = a.k_max - (k0 + R);
       a.cnt[b] = left < GMPC_LS_NEXT ? left : GMPC_LS_NEXT;
@@ -526,7 +531,8 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
                      a.obj_step);
   for (int r = 0; r < rounds; ++r) {
     hipLaunchKernelGGL(k_ls_place, dim3(1), dim3(1024), 0, s, a.B, w.cnt, w.kfirst, w.item_b[0], w.item_k[0],
-                       w.slot, w.counts + r, w.counts + GMPC_LS_ROUNDS_MAX);
+                       w.slot, w.counts + r, w.counts + GMPC_LS_ROUNDS_MAX,
+                       w.counts + GMPC_LS_ROUNDS_MAX + 1 + 24 + (r < GMPC_LS_STATS - 24 ? r : GMPC_LS_STATS - 25));
     a.item_b = w.item_b[0]; a.item_k = w.item_k[0]; a.nitems = w.counts + r; a.objc = w.objc;
     const long max_items = (long)a.B * (r == 0 ? GMPC_LS_ITEMS : GMPC_LS_NEXT);
     const int lsgrid = (int)((max_items + GMPC_TB - 1) / GMPC_TB);
@@ -545,6 +551,7 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
     d.objc = w.objc; d.Xc = a.Xc; d.Uc = a.Uc; d.maskc = a.maskc;
     d.X = a.X; d.U = a.Uio; d.masks = a.masks;
     d.obj = a.obj; d.obj_step = a.obj_step; d.U_step = a.U_step; d.alpha = a.alpha;
+    d.stats = w.counts + GMPC_LS_ROUNDS_MAX + 1;
     hipLaunchKernelGGL(k_ls_decide, dim3(a.B), dim3(GMPC_THREADS), 0, s, d);
   }
   return 0;

@@ -278,6 +278,17 @@ class Engine:
         """Candidate rollouts evaluated by the line searches of the last ilqr_solve."""
         return int(self.lib.gmpc_linesearch_candidates(self.ctx))
 
+    def linesearch_stats(self):
+        """Counters of the last ilqr_solve's line searches: how many accepted alpha_0 / 2^k (list `accepted`,
+        k = 0..15), how many ran out of step sizes, candidate rollouts per speculative round."""
+        out = (C.c_long * 64)()
+        _lib.check(self.lib.gmpc_linesearch_stats(self.ctx, out, 64))
+        v = list(out)
+        rounds = v[24:64]
+        while rounds and rounds[-1] == 0:
+            rounds.pop()
+        return {"accepted": v[:16], "exhausted": v[16], "round_items": rounds}
+
     PROF_SLOTS = ("rollout", "linearize", "terminal", "riccati", "linesearch", "lstm_fwd", "head",
                   "lstm_bwd", "wgrad", "adam")
 

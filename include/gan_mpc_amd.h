@@ -261,6 +261,12 @@ int gmpc_bgemm_tn(gmpc_ctx* ctx, int batch, int M, int N, int K, const float* X,
  * evaluated -- the work count behind bench.py's secondary roofline.  Synchronises the device. */
 long gmpc_linesearch_candidates(gmpc_ctx* ctx);
 
+/* Counters of the line searches of the last gmpc_ilqr_solve, `n` <= 64 values: out[k], k = 0..15 = line searches
+ * that accepted the step alpha_0 / 2^k (trajax line_search_ddp as called from policy/optimizers.py:19), out[16] =
+ * line searches that ran out of step sizes, out[24 + r] = candidate rollouts of speculative round r.  Diagnostic
+ * (bench.py reports it); synchronises the device. */
+int gmpc_linesearch_stats(gmpc_ctx* ctx, long* out, int n);
+
 /* Stream overlap hook.  `hip_event` (a hipEvent_t, or NULL to clear) is recorded on the backward pass's stream
  * right after the Jacobian chain of gmpc_lqr_backward(_after_rollout) / of every iteration of gmpc_ilqr_solve has
  * been enqueued, i.e. before the terminal quadratisation and the Riccati sweep (large-state path: before the
