@@ -109,13 +109,14 @@ struct __attribute__((packed, aligned(4))) bt_f4 { float x, y, z, w; };
 struct __attribute__((packed, aligned(4))) bt_f2 { float x, y; };
 
 // NTJ = 2: 64 columns per wave, 8-byte loads (twice the waves: fills the chip when batch * width / 128 does not)
-template <bool WIDE_X, int NTJ, int RD>
+// NS = 2: both 32-column strips of a thin operand of 33..64 columns in one wave (the wide operand is read once)
+template <bool WIDE_X, int NTJ, int RD, int NS>
 __global__ __launch_bounds__(GMPC_THREADS) void k_bthin(BgemmArgs a) {
   constexpr int GW = 32 * NTJ;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int Wd = WIDE_X ? a.M : a.N, Th = WIDE_X ? a.N : a.M;       // wide / thin extents
-  const int groups = (Wd + GW - 1) / GW, strips = (Th + 31) >> 5;
+  const int groups = (Wd + GW - 1) / GW, strips = (Th + 32 * NS - 1) / (32 * NS);
   const long total = (long)a.batch * groups * strips;
   const long item = (long)blockIdx.x * (GMPC_THREADS / 64) + wave;
   if (item >= total) return;
@@ -127,26 +128,34 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bthin(BgemmArgs a) {
   const float* Tp = (WIDE_X ? a.Y + (size_t)b * a.sy : a.X + (size_t)b * a.sx);
   const int ldw = WIDE_X ? a.ldx : a.ldy, ldt = WIDE_X ? a.ldy : a.ldx;
   const int K = a.K;
-  // this lane's 4 wide columns and its thin column
+  // this lane's NTJ wide columns and its thin column(s)
   const int wc = GW * g + NTJ * l31;
   // lanes past the width read the row's last 16 bytes instead (never out of the matrix); when the width is not
   // a multiple of 4 one lane straddles the edge and finds its columns `sh` places further up in that load
   const int wcl = min(wc, max(Wd - NTJ, 0));
   const int sh = wc - wcl;
   const bool ragged = (Wd & (NTJ - 1)) != 0;        // (uniform)
-  const int tc = 32 * st + l31;
-  const bool tok = tc < Th;
+  const int tc0 = 32 * NS * st + l31;
   const float* wrow = Wp + wcl;
-  const float* trow = Tp + (tok ? tc : 0);
-  f32x16 acc[NTJ];
+  const float* trow[NS];
+  bool tok[NS];
 #pragma unroll
-  for (int j = 0; j < NTJ; ++j)
+  for (int q = 0; q < NS; ++q) {
+    tok[q] = tc0 + 32 * q < Th;
+    trow[q] = Tp + (tok[q] ? tc0 + 32 * q : 0);
+  }
+  f32x16 acc[NS][NTJ];
 #pragma unroll
-    for (int rg = 0; rg < 16; ++rg) acc[j][rg] = 0.f;
+  for (int q = 0; q < NS; ++q)
+#pragma unroll
+    for (int j = 0; j < NTJ; ++j)
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) acc[q][j][rg] = 0.f;
+  struct Tq { float v[NS]; };
   bt_f4 wq[RD];
-  float tq[RD];
+  Tq tq[RD];
   const int KS = (K + 1) >> 1;
-  auto issue = [&](int ks, bt_f4& wv, float& tv) {
+  auto issue = [&](int ks, bt_f4& wv, Tq& tv) {
     const int r = min(2 * ks + half, K - 1);
     if (NTJ == 4) {
       wv = *reinterpret_cast<const bt_f4*>(wrow + (size_t)r * ldw);
@@ -154,10 +163,11 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bthin(BgemmArgs a) {
       const bt_f2 q = *reinterpret_cast<const bt_f2*>(wrow + (size_t)r * ldw);
       wv.x = q.x; wv.y = q.y;
     }
-    tv = trow[(size_t)r * ldt];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) tv.v[q] = trow[q][(size_t)r * ldt];
   };
-  auto mult = [&](int ks, bt_f4 wv, float tv) {
-    const float t = (tok && 2 * ks + half < K) ? tv : 0.f;
+  auto mult = [&](int ks, bt_f4 wv, const Tq& tv) {
+    const bool rok = 2 * ks + half < K;
     if (ragged) {
       const bt_f4 q = wv;
       if (NTJ == 4) {
@@ -170,9 +180,13 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bthin(BgemmArgs a) {
     }
     const float wj[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-    for (int j = 0; j < NTJ; ++j)
-      acc[j] = WIDE_X ? __builtin_amdgcn_mfma_f32_32x32x2f32(wj[j], t, acc[j], 0, 0, 0)
-                      : __builtin_amdgcn_mfma_f32_32x32x2f32(t, wj[j], acc[j], 0, 0, 0);
+    for (int q = 0; q < NS; ++q) {
+      const float t = (tok[q] && rok) ? tv.v[q] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NTJ; ++j)
+        acc[q][j] = WIDE_X ? __builtin_amdgcn_mfma_f32_32x32x2f32(wj[j], t, acc[q][j], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x2f32(t, wj[j], acc[q][j], 0, 0, 0);
+    }
   };
 #pragma unroll
   for (int i = 0; i < RD; ++i) issue(min(i, KS - 1), wq[i], tq[i]);
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bthin(BgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < RD; ++i) {
       const bt_f4 wv = wq[i];
-      const float tv = tq[i];
+      const Tq tv = tq[i];
       issue(min(ks + RD + i, KS - 1), wq[i], tq[i]);      // (past the end: the last k-step again, not used)
       __builtin_amdgcn_sched_barrier(0);
       mult(ks + i, wv, tv);
@@ -194,29 +208,55 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_bthin(BgemmArgs a) {
   // epilogue: accumulator row i of tile j <-> wide column GW g + NTJ i + j (WIDE_X: a row of C), column l31 <->
   // thin column (WIDE_X) / wide columns GW g + NTJ l31 + j (a run of NTJ floats of row i of C otherwise)
 #pragma unroll
-  for (int rg = 0; rg < 16; ++rg) {
-    const int i = (rg & 3) + 8 * (rg >> 2) + 4 * half;
-    if (WIDE_X) {
+  for (int q = 0; q < NS; ++q) {
+    const int tc = tc0 + 32 * q;
 #pragma unroll
-      for (int j = 0; j < NTJ; ++j) {
-        const int row = GW * g + NTJ * i + j;
-        if (row < a.M && tok) {
-          float* cp = a.C + (size_t)b * a.sc + (size_t)row * a.ldc + tc;
-          float v = a.alpha * acc[j][rg];
-          if (a.beta != 0.f) v = fmaf(a.beta, *cp, v);
-          *cp = v;
-        }
-      }
-    } else {
-      const int row = 32 * st + i;
-      if (row < a.M) {
-        float* cp = a.C + (size_t)b * a.sc + (size_t)row * a.ldc + wc;
+    for (int rg = 0; rg < 16; ++rg) {
+      const int i = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+      if (WIDE_X) {
 #pragma unroll
         for (int j = 0; j < NTJ; ++j) {
-          if (wc + j < a.N) {
-            float v = a.alpha * acc[j][rg];
-            if (a.beta != 0.f) v = fmaf(a.beta, cp[j], v);
-            cp[j] = v;
+          const int row = GW * g + NTJ * i + j;
+          if (row < a.M && tok[q]) {
+            float* cp = a.C + (size_t)b * a.sc + (size_t)row * a.ldc + tc;
+            float v = a.alpha * acc[q][j][rg];
+            if (a.beta != 0.f) v = fmaf(a.beta, *cp, v);
+            *cp = v;
+          }
+        }
+      } else {
+        const int row = 32 * NS * st + 32 * q + i;
+        if (row < a.M) {
+          float* cp = a.C + (size_t)b * a.sc + (size_t)row * a.ldc + wc;
+          if (wc + NTJ <= a.N) {             // the lane's NTJ columns as one store (a row of C is contiguous)
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < NTJ; ++j) v[j] = a.alpha * acc[q][j][rg];
+            if (NTJ == 4) {
+              bt_f4* c4 = reinterpret_cast<bt_f4*>(cp);
+              if (a.beta != 0.f) {
+                const bt_f4 o = *c4;
+                v[0] = fmaf(a.beta, o.x, v[0]); v[1] = fmaf(a.beta, o.y, v[1]);
+                v[2] = fmaf(a.beta, o.z, v[2]); v[3] = fmaf(a.beta, o.w, v[3]);
+              }
+              *c4 = bt_f4{v[0], v[1], v[2], v[3]};
+            } else {
+              bt_f2* c2 = reinterpret_cast<bt_f2*>(cp);
+              if (a.beta != 0.f) {
+                const bt_f2 o = *c2;
+                v[0] = fmaf(a.beta, o.x, v[0]); v[1] = fmaf(a.beta, o.y, v[1]);
+              }
+              *c2 = bt_f2{v[0], v[1]};
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < NTJ; ++j) {
+              if (wc + j < a.N) {
+                float v = a.alpha * acc[q][j][rg];
+                if (a.beta != 0.f) v = fmaf(a.beta, cp[j], v);
+                cp[j] = v;
+              }
+            }
           }
         }
       }
@@ -474,6 +514,34 @@ static void launch_lds(const BgemmArgs& a, hipStream_t s) {
 }
 
 void gmpc_launch_bgemm_tn(const BgemmArgs& a, hipStream_t s) {
+  // a thin product whose wide operand is worth streaming (k_bthin)
+  {
+    static const bool off = [] { const char* e = getenv("GMPC_BTHIN"); return e != nullptr && e[0] == '0'; }();
+    const bool widex = a.N <= 64 && a.M >= 128, widey = a.M <= 64 && a.N >= 128;
+    if (!off && (widex || widey) && a.K >= 2 * BT_RD && a.E == nullptr && a.rowmask == nullptr && a.K2 == 0 &&
+        a.K3 == 0 && !a.upper_only) {
+      const int Wd = widex ? a.M : a.N, Th = widex ? a.N : a.M;
+      // 128 columns per wave (16-byte loads) when that still gives every SIMD a few waves, else 64 (8-byte loads,
+      // twice the waves: PB at the C4 shard is 1536 waves of 128 columns -- 1.5 per SIMD, 0.084 ms -- or 3072 of
+      // 64, 0.073 ms); a thin operand of 33..64 columns goes through one wave as two strips
+      static const int ntj_env = [] { const char* e = getenv("GMPC_BTHIN_NTJ"); return e ? atoi(e) : 0; }();
+      static const int ns_env = [] { const char* e = getenv("GMPC_BTHIN_NS"); return e ? atoi(e) : 0; }();
+      const int ns = ns_env == 1 ? 1 : Th > 32 ? 2 : 1;
+      const long waves4 = (long)a.batch * ((Wd + 127) / 128) * ((Th + 32 * ns - 1) / (32 * ns));
+      // (two strips x four tiles are 268 registers, one wave per SIMD: 0.387 ms against 0.360 with two tiles for
+      // the [64 x 1088] x K = 200 products of C5)
+      const int ntj = ntj_env == 2 || ntj_env == 4 ? ntj_env : (waves4 < 4096 || ns == 2) ? 2 : 4;
+      const long total = (long)a.batch * ((Wd + 32 * ntj - 1) / (32 * ntj)) * ((Th + 32 * ns - 1) / (32 * ns));
+      const dim3 grid((unsigned)((total + 3) / 4)), blk(GMPC_THREADS);
+#define BT_LAUNCH(WX, NJ, S) hipLaunchKernelGGL((k_bthin<WX, NJ, BT_RD, S>), grid, blk, 0, s, a)
+#define BT_LAUNCH2(WX, NJ) do { if (ns == 2) BT_LAUNCH(WX, NJ, 2); else BT_LAUNCH(WX, NJ, 1); } while (0)
+      if (widex) { if (ntj == 2) BT_LAUNCH2(true, 2); else BT_LAUNCH2(true, 4); }
+      else       { if (ntj == 2) BT_LAUNCH2(false, 2); else BT_LAUNCH2(false, 4); }
+#undef BT_LAUNCH2
+#undef BT_LAUNCH
+      return;
+    }
+  }
   // (the epilogue extras and the second K-segment exist in the LDS-staged kernel only)
   if ((a.M > 32 && a.N > 64) || a.E != nullptr || a.rowmask != nullptr || a.K2 > 0 || a.K3 > 0) {
     // column blocks of 128 / 192 / 256: the one that pads N least (ties: the widest)
@@ -497,27 +565,6 @@ void gmpc_launch_bgemm_tn(const BgemmArgs& a, hipStream_t s) {
       default: launch_lds<2, 4>(a, s); break;
     }
     return;
-  }
-  // a thin product whose wide operand is worth streaming (k_bthin)
-  {
-    static const bool off = [] { const char* e = getenv("GMPC_BTHIN"); return e != nullptr && e[0] == '0'; }();
-    const bool widex = a.N <= 64 && a.M >= 128, widey = a.M <= 64 && a.N >= 128;
-    if (!off && (widex || widey) && a.K >= 2 * BT_RD) {
-      const int Wd = widex ? a.M : a.N, Th = widex ? a.N : a.M;
-      // 128 columns per wave (16-byte loads) when that still gives every SIMD a few waves, else 64 (8-byte loads,
-      // twice the waves: PB at the C4 shard is 1536 waves of 128 columns -- 1.5 per SIMD, 0.084 ms -- or 3072 of
-      // 64, 0.073 ms)
-      static const int ntj_env = [] { const char* e = getenv("GMPC_BTHIN_NTJ"); return e ? atoi(e) : 0; }();
-      const long waves4 = (long)a.batch * ((Wd + 127) / 128) * ((Th + 31) / 32);
-      const int ntj = ntj_env == 2 || ntj_env == 4 ? ntj_env : waves4 < 4096 ? 2 : 4;
-      const long total = (long)a.batch * ((Wd + 32 * ntj - 1) / (32 * ntj)) * ((Th + 31) / 32);
-      const dim3 grid((unsigned)((total + 3) / 4)), blk(GMPC_THREADS);
-#define BT_LAUNCH(WX, NJ) hipLaunchKernelGGL((k_bthin<WX, NJ, BT_RD>), grid, blk, 0, s, a)
-      if (widex) { if (ntj == 2) BT_LAUNCH(true, 2); else BT_LAUNCH(true, 4); }
-      else       { if (ntj == 2) BT_LAUNCH(false, 2); else BT_LAUNCH(false, 4); }
-#undef BT_LAUNCH
-      return;
-    }
   }
   // a thin product: one wave per strip (the second K-segment is not supported here)
   const int tiles = (a.N + 31) / 32;
