@@ -461,7 +461,8 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
       const int col = n0 + (wn * WNT + j) * 32 + l31;
       if (col < a.N) {
         // the addend of the whole tile is requested before the first store (E may alias C as far as the
-        // compiler knows: interleaved, every load would wait behind the stores before it)
+        // compiler knows: interleaved, every load would wait behind the stores before it).  (All tiles of the
+        // wave at once -- one memory round trip per block instead of four -- measured slower: C5 2.059 vs 2.025 s.)
         float ev[16];
         const bool has_e = a.E != nullptr && col < a.En;
 #pragma unroll
@@ -490,6 +491,9 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
 #ifndef GMPC_BG_KC_VEC
 #define GMPC_BG_KC_VEC 16
 #endif
+#ifndef GMPC_BG_KC_VEC22            // stage depth of the 128 x 128 blocks with 16-byte staging (C5: 2.025 s with 8, 2.044 with 16, 2.161 with 32)
+#define GMPC_BG_KC_VEC22 8
+#endif
 #ifndef GMPC_BG_KC
 #define GMPC_BG_KC 8
 #endif
@@ -506,7 +510,7 @@ static void launch_lds(const BgemmArgs& a, hipStream_t s) {
                    al4(a.K2 ? a.Y2 : nullptr, a.sy2, a.ldy2) && al4(a.K3 ? a.X3 : nullptr, a.sx3, a.ldx3) &&
                    al4(a.K3 ? a.Y3 : nullptr, a.sy3, a.ldy3);
   if (vec)
-    hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT == 3 ? 2 : WNT, GMPC_BG_KC_VEC, true>), dim3((unsigned)(per * 8)),
+    hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT == 3 ? 2 : WNT, WNT == 2 ? GMPC_BG_KC_VEC22 : GMPC_BG_KC_VEC, true>), dim3((unsigned)(per * 8)),
                        dim3(GMPC_THREADS), 0, s, a);
   else
     hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT, GMPC_BG_KC>), dim3((unsigned)(per * 8)), dim3(GMPC_THREADS), 0,
@@ -559,6 +563,8 @@ void gmpc_launch_bgemm_tn(const BgemmArgs& a, hipStream_t s) {
       }
       if (waste < 0 || padded <= waste) { waste = padded; best = w; }
     }
+    static const int w_env = [] { const char* e = getenv("GMPC_BG_UPPER_W"); return e ? atoi(e) : 0; }();
+    if (a.upper_only && w_env >= 2 && w_env <= 4) best = w_env;      // (A/B timing of the block width)
     switch (best) {
       case 2: launch_lds<2, 2>(a, s); break;
       case 3: launch_lds<2, 3>(a, s); break;
@@ -606,15 +612,179 @@ struct BigStepArgs {
   float* gn2;            // [B]           running sum of squared control gradients
   const int* active;
   float* K; float* k; float* grad; float* adj;   // [B][T][m][n], [B][T][m], [B][T][m], [B][T+1][n]
+  int solve_valu;        // mode 0: the gain solve on the vector pipe (the form before big_solve_mfma; GMPC_BIG_SOLVE=valu)
 };
 
+// 4-row blocks of the matrix-pipe gain solve (big_solve_mfma) for m controls: the instantiated size that holds m
+static int big_solve_blocks(int m) { return m <= 8 ? 2 : m <= 20 ? 5 : m <= 32 ? 8 : 16; }
 static size_t big_step_lds(int n, int m, int h) {
   const size_t MP = (size_t)((m + 7) & ~7);     // solve columns and the blocked solve's copies are padded to 8
+  // the solve's work area: one column per thread + the padded copies of the vector form, or the operand
+  // fragments + the padded factor of the matrix-pipe form
+  const size_t MB = big_solve_blocks(m), KCH = (4 * MB + 15) / 16;
+  const size_t valu = MP * GMPC_THREADS + ((m & 7) ? 3 : 1) * MP * MP + 4, mfma = 3 * MB * KCH * 64 + 16 * MB * MB + 4;
   return ((size_t)2 * m * m + 5 * (size_t)n + 7 * (size_t)m + 16 + 2 * (size_t)h + 2 * GMPC_THREADS +
-          MP * GMPC_THREADS + ((m & 7) ? 3 : 1) * MP * MP + 4) * sizeof(float);
+          (valu > mfma ? valu : mfma)) * sizeof(float);
 }
 
+// ------------------------------------------------------------------------------------------------
+// [K_t] = -(G + delta I)^-1 H, V = H + G K / 2 of k_big_step (mode 0) with the matrix pipe doing the
+// multiply-subtracts.  One column of H per lane as before; the column lives in REGISTERS (y[4 MB]) and is the B
+// operand of v_mfma_f32_4x4x1_16B_f32: d[i] += A[i][k] * y[k] for the 4 rows of a block and the lane's own column,
+// A = 16 consecutive k of (-L), (-L^T) or G for the block's 4 rows in one VGPR ([k][4 rows] fragments built once
+// per trajectory in LDS, broadcast with cbsz / abid as in the trajectory kernels).  What stays on the vector
+// pipe is the 4 x 4 triangle on the diagonal of every block (6 multiply-subtracts and 4 divisions per block and
+// sweep).  Same operations as the vector form (exact fp32 FMAs, divisions by the diagonal); the multiply-subtracts
+// of a row are summed in two interleaved chains (even / odd k) instead of one.
+// At the C5 shard (m = 64, n = 1024) the vector form spent 2.3 of k_big_step's 2.8 ms here (0.4 LDS reads per
+// multiply-subtract); this form: 2 300 MFMAs of 8 cycles per 64 columns.
+// ------------------------------------------------------------------------------------------------
+template <int MB>
+__device__ __forceinline__ void big_solve_mfma(int n, int m, int nm, const float* L, const float* G,
+                                               const float* __restrict__ HG, float* work, float* __restrict__ Kt,
+                                               float* __restrict__ KV, float* __restrict__ VK) {
+  constexpr int MP = 4 * MB, KCH = (MP + 15) / 16;
+  float* const AsF = work;                       // [MB][KCH][16 k][4 rows]: -L below the block's diagonal block
+  float* const AsB = AsF + MB * KCH * 64;        // -L^T right of it
+  float* const AsG = AsB + MB * KCH * 64;        // G
+  float* const Lp = AsG + MB * KCH * 64;         // [MP][MP] L padded with an identity block
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int e = tid; e < MB * KCH * 64; e += GMPC_THREADS) {
+    const int l = e & 63, kc = (e >> 6) % KCH, ib = (e >> 6) / KCH;
+    const int row = 4 * ib + (l & 3), k = 16 * kc + (l >> 2);
+    const bool in = row < m && k < m;
+    AsF[e] = (in && k < 4 * ib) ? -L[row * m + k] : 0.f;
+    AsB[e] = (in && k >= 4 * ib + 4) ? -L[k * m + row] : 0.f;
+    AsG[e] = in ? G[row * m + k] : 0.f;
+  }
+  for (int e = tid; e < MP * MP; e += GMPC_THREADS) {
+    const int i = e / MP, k = e - i * MP;
+    Lp[e] = (i < m && k < m) ? L[i * m + k] : (i == k ? 1.f : 0.f);
+  }
+  __syncthreads();
+  const int m_in = m;
+  for (int c0 = 0; c0 + 64 * wave < n; c0 += GMPC_THREADS) {          // (uniform per wave: the MFMAs need all lanes)
+    // (m made opaque per iteration: the ~200 uniform "row < m" tests below are compared where they are used
+    // instead of being hoisted out of the loop into -- and spilled from -- the scalar registers)
+    int m = m_in;
+    asm volatile("" : "+s"(m));
+    const int c = c0 + tid;
+    const bool cok = c < n;
+    const float* Hc = HG + (cok ? c : n - 1);
+    // (rows through walking pointers: 64 loop-invariant row offsets would be hoisted into -- and spilled from --
+    // the scalar registers)
+    float y[MP];
+    {
+      const float* hp = Hc;
+#pragma unroll
+      for (int i = 0; i < MP; ++i) {
+        y[i] = i < m ? *hp : 0.f;
+        if (i + 1 < m) hp += nm;
+      }
+    }
+    // ---- L y = H: block ib needs y[0 .. 4 ib - 1]
+    rw_static_for<MB>([&](auto ibc) __attribute__((always_inline)) {
+      constexpr int ib = decltype(ibc)::value;
+      f32x4_t d0 = {y[4 * ib], y[4 * ib + 1], y[4 * ib + 2], y[4 * ib + 3]}, d1 = {0.f, 0.f, 0.f, 0.f};
+      rw_static_for<(4 * ib + 15) / 16>([&](auto kcc) __attribute__((always_inline)) {
+        constexpr int kc = decltype(kcc)::value;
+        const float ar = AsF[(ib * KCH + kc) * 64 + lane];
+        rw_static_for<16>([&](auto kkc) __attribute__((always_inline)) {
+          constexpr int k = 16 * kc + decltype(kkc)::value;
+          if constexpr (k < 4 * ib) {
+            if constexpr (k & 1) rw_mfma<k>(d1, ar, y[k]);
+            else rw_mfma<k>(d0, ar, y[k]);
+          }
+        });
+      });
+      const float* Ld = Lp + (4 * ib) * MP + 4 * ib;
+      float v0 = d0[0] + d1[0], v1 = d0[1] + d1[1], v2 = d0[2] + d1[2], v3 = d0[3] + d1[3];
+      v0 = v0 / Ld[0];
+      v1 = (v1 - Ld[MP] * v0) / Ld[MP + 1];
+      v2 = ((v2 - Ld[2 * MP] * v0) - Ld[2 * MP + 1] * v1) / Ld[2 * MP + 2];
+      v3 = (((v3 - Ld[3 * MP] * v0) - Ld[3 * MP + 1] * v1) - Ld[3 * MP + 2] * v2) / Ld[3 * MP + 3];
+      y[4 * ib] = v0; y[4 * ib + 1] = v1; y[4 * ib + 2] = v2; y[4 * ib + 3] = v3;
+    });
+    // ---- L^T x = y: block ib needs x[4 ib + 4 ..]
+    rw_static_for<MB>([&](auto ibr) __attribute__((always_inline)) {
+      constexpr int ib = MB - 1 - decltype(ibr)::value;
+      f32x4_t d0 = {y[4 * ib], y[4 * ib + 1], y[4 * ib + 2], y[4 * ib + 3]}, d1 = {0.f, 0.f, 0.f, 0.f};
+      constexpr int kc0 = (4 * ib + 4) / 16;
+      rw_static_for<KCH - kc0>([&](auto kcc) __attribute__((always_inline)) {
+        constexpr int kc = kc0 + decltype(kcc)::value;
+        const float ar = AsB[(ib * KCH + kc) * 64 + lane];
+        rw_static_for<16>([&](auto kkc) __attribute__((always_inline)) {
+          constexpr int k = 16 * kc + decltype(kkc)::value;
+          if constexpr (k >= 4 * ib + 4 && k < MP) {
+            if constexpr (k & 1) rw_mfma<k>(d1, ar, y[k]);
+            else rw_mfma<k>(d0, ar, y[k]);
+          }
+        });
+      });
+      const float* Ld = Lp + (4 * ib) * MP + 4 * ib;      // U[r][q] = L[q][r]
+      float v0 = d0[0] + d1[0], v1 = d0[1] + d1[1], v2 = d0[2] + d1[2], v3 = d0[3] + d1[3];
+      v3 = v3 / Ld[3 * MP + 3];
+      v2 = (v2 - Ld[3 * MP + 2] * v3) / Ld[2 * MP + 2];
+      v1 = ((v1 - Ld[2 * MP + 1] * v2) - Ld[3 * MP + 1] * v3) / Ld[MP + 1];
+      v0 = (((v0 - Ld[MP] * v1) - Ld[2 * MP] * v2) - Ld[3 * MP] * v3) / Ld[0];
+      y[4 * ib] = v0; y[4 * ib + 1] = v1; y[4 * ib + 2] = v2; y[4 * ib + 3] = v3;
+    });
+#pragma unroll
+    for (int i = 0; i < MP; ++i) y[i] = -y[i];            // K's column
+    // ---- V = H + G K / 2, outputs
+    const float* hp = Hc;
+    const size_t co = cok ? c : 0, mn = (size_t)m * n;
+    float* kp = Kt + co;
+    float* kvp = KV + co;
+    float* vkp = VK + co;
+    rw_static_for<MB>([&](auto ibc) __attribute__((always_inline)) {
+      constexpr int ib = decltype(ibc)::value;
+      f32x4_t d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+      float hr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        hr[r] = 4 * ib + r < m ? *hp : 0.f;
+        if (4 * ib + r + 1 < m) hp += nm;
+      }
+      rw_static_for<KCH>([&](auto kcc) __attribute__((always_inline)) {
+        constexpr int kc = decltype(kcc)::value;
+        const float ar = AsG[(ib * KCH + kc) * 64 + lane];
+        rw_static_for<16>([&](auto kkc) __attribute__((always_inline)) {
+          constexpr int k = 16 * kc + decltype(kkc)::value;
+          if constexpr (k < MP) {
+            if constexpr (k & 1) rw_mfma<k>(d1, ar, y[k]);
+            else rw_mfma<k>(d0, ar, y[k]);
+          }
+        });
+      });
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = 4 * ib + r;
+        if (i < m && cok) {
+          const float kic = y[i];
+          const float vic = fmaf(0.5f, d0[r] + d1[r], hr[r]);
+          *kp = kic;
+          *kvp = kic;
+          kvp[mn] = vic;
+          *vkp = vic;
+          vkp[mn] = kic;
+        }
+        kp += n; kvp += n; vkp += n;
+      }
+    });
+  }
+}
+
+#ifdef GMPC_BIGSTEP_STAMPS
+#define BS_STAMP(i) { __syncthreads(); if (threadIdx.x == 0) bs_t[i] = __builtin_readcyclecounter(); }
+#else
+#define BS_STAMP(i)
+#endif
 __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
+#ifdef GMPC_BIGSTEP_STAMPS
+  unsigned long long bs_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  BS_STAMP(0)
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = a.n, m = a.m, T = a.T, t = a.t, nm = n + m;
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -674,6 +844,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     qv[i] = m1 ? a.lx[((size_t)b * (T + 1) + t) * n + i] : w1 * dv[i] / s;
   for (int j = tid; j < m; j += blockDim.x) rv[j] = m1 ? 0.f : w0 * uv[j] / su;
   __syncthreads();
+  BS_STAMP(1)
   const bool lowrank = a.Vt != nullptr;
   const float* Vt = lowrank ? a.Vt + (size_t)b * a.h * nm : nullptr;
   if (lowrank) {
@@ -711,6 +882,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     }
     __syncthreads();
   }
+  BS_STAMP(2)
   // g_t = r + B^T lam ; h = r + B^T p : thread (rp, j) sums rows rp, rp + RP, ... of column j of B
   // (low-rank form: B^T v = Vu (W_L v), rows of V^T instead of rows of B)
   {
@@ -748,6 +920,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
       gsq[tid] = gs * gs;
     }
   }
+  BS_STAMP(3)
   // lam_t = q + A^T lam ; pa = A^T p        (column c of A is read coalesced across threads; four columns of
   // a thread and two rows at a time: 8 loads in flight instead of one)
   for (int c0 = tid; c0 < n; c0 += 4 * blockDim.x) {
@@ -789,6 +962,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
       if (!m1) a.adj[((size_t)b * (T + 1) + t) * n + c] = ln;
     }
   }
+  BS_STAMP(4)
   // G = sym(R + B^T P B)
   for (int e = tid; e < m * m; e += blockDim.x) {
     const int i = e / m, j = e - i * m;
@@ -811,6 +985,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   float* VK = a.VK + (size_t)b * 2 * m * n;
   float* y = ycol + tid;
   if (!m1) {
+    BS_STAMP(5)
     // Cholesky of G + 1e-8 I in L (lower), column by column; NaN on a non-positive pivot
     for (int e = tid; e < m * m; e += blockDim.x) L[e] = G[e] + ((e / m) == (e % m) ? 1e-8f : 0.f);
     __syncthreads();
@@ -820,16 +995,40 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
       const float d = L[j * m + j];
       for (int i = j + 1 + tid; i < m; i += blockDim.x) L[i * m + j] /= d;
       __syncthreads();
-      // trailing update of the lower triangle: L[i][k] -= L[i][j] L[k][j], j < k <= i
-      const int rem = m - j - 1;
-      for (int e = tid; e < rem * rem; e += blockDim.x) {
-        const int i = j + 1 + e / rem, k = j + 1 + e % rem;
-        if (k <= i) L[i * m + k] -= L[i * m + j] * L[k * m + j];
+      // trailing update of the lower triangle: L[i][k] -= L[i][j] L[k][j], j < k <= i; thread (tid / 16, tid % 16)
+      // walks rows and columns in steps of 16 (no integer division by the shrinking size in the loop)
+      for (int i = j + 1 + (tid >> 4); i < m; i += GMPC_THREADS / 16) {
+        const float lij = L[i * m + j];
+        for (int k = j + 1 + (tid & 15); k <= i; k += 16) L[i * m + k] -= lij * L[k * m + j];
       }
       __syncthreads();
     }
-    // [K k] = -(G + delta I)^-1 [H h], one right-hand-side column per thread (column n is h); the
-    // thread keeps its column in LDS (ycol[i][tid])
+    BS_STAMP(6)
+    // [K k] = -(G + delta I)^-1 [H h]
+    if (!a.solve_valu && m <= 64) {
+      // the right-hand side h: wave 0 across its lanes (see the vector form below); the n columns of H: one
+      // per lane, the multiply-subtracts on the matrix pipe (big_solve_mfma)
+      if (tid < 64) {
+        float v = tid < m ? hv[tid] : 0.f, yv = 0.f;
+        for (int k = 0; k < m; ++k) {
+          const float yk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)) / L[k * m + k];
+          if (tid == k) yv = yk;
+          if (tid > k && tid < m) v -= L[tid * m + k] * yk;
+        }
+        for (int k = m - 1; k >= 0; --k) {
+          const float xk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yv), k)) / L[k * m + k];
+          if (tid == k) yv = xk;
+          if (tid < k) yv -= L[k * m + tid] * xk;
+        }
+        if (tid < m) { kv[tid] = -yv; a.k[bt * m + tid] = -yv; }
+      }
+      if (m <= 8) big_solve_mfma<2>(n, m, nm, L, G, HG, ycol, Kt, KV, VK);
+      else if (m <= 20) big_solve_mfma<5>(n, m, nm, L, G, HG, ycol, Kt, KV, VK);
+      else if (m <= 32) big_solve_mfma<8>(n, m, nm, L, G, HG, ycol, Kt, KV, VK);
+      else big_solve_mfma<16>(n, m, nm, L, G, HG, ycol, Kt, KV, VK);
+    } else
+    // the vector form: one right-hand-side column per thread (column n is h); the thread keeps its column in
+    // LDS (ycol[i][tid])
     {
       // blocks of 8 rows share the loads of the solved part of the column and read their rows of L (L^T in
       // the backward sweep) and G 16 bytes at a time -- 0.4 LDS reads per multiply-subtract instead of 2 (the
@@ -1012,6 +1211,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
       }
     }
   }
+  BS_STAMP(7)
   __syncthreads();
   for (int i = tid; i < m; i += blockDim.x) {
     float v = 0.f;
@@ -1028,6 +1228,13 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     }
     a.pvec[(size_t)b * n + c] = (((m1 ? 0.f : qv[c]) + pa[c]) + v1) + v2;
   }
+#ifdef GMPC_BIGSTEP_STAMPS
+  BS_STAMP(8)
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.t == a.T - 2)
+    printf("k_big_step cycles: load %llu | y=WL v %llu | g,h %llu | lam,pa %llu | G %llu | chol %llu | solve %llu | gk,p %llu | total %llu\n",
+           bs_t[1] - bs_t[0], bs_t[2] - bs_t[1], bs_t[3] - bs_t[2], bs_t[4] - bs_t[3], bs_t[5] - bs_t[4], bs_t[6] - bs_t[5],
+           bs_t[7] - bs_t[6], bs_t[8] - bs_t[7], bs_t[8] - bs_t[0]);
+#endif
 }
 
 // P = Q_t + T1 on the upper triangle, mirrored into the lower one: tile (I, J) with I <= J (64 x 64) is read
@@ -1262,6 +1469,8 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
     a.X = X; a.U = U; a.goal = goal; a.ng = w.ng; a.mpc_w = mpc_w; a.ABt = w.ABt; a.HG = w.HG; a.KV = w.KV; a.VK = w.VK;
     a.pvec = w.pvec; a.lam = w.lam; a.sbuf = w.sbuf; a.gn2 = w.gn2; a.active = active;
     a.K = K; a.k = k; a.grad = grad; a.adj = adj;
+    static const bool solve_valu = [] { const char* e = getenv("GMPC_BIG_SOLVE"); return e != nullptr && strcmp(e, "valu") == 0; }();
+    a.solve_valu = solve_valu ? 1 : 0;
     hipLaunchKernelGGL(k_big_step, dim3(B), dim3(GMPC_THREADS), lds, s, a);
     // T1 = A^T (PA) + [K; V]^T [V; K], upper blocks only   (low-rank form: P + Vx Z + Z^T Vx^T)
     BgemmArgs g = lowrank ? gemm(n, n, h, w.Vt, shnm, nm, w.W2b, shnm, nm, w.T1, snn, n)
