@@ -299,6 +299,9 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
   if (a.active != nullptr && a.active[b] == 0) return;
   const int m0 = mi * BM, n0 = ni * BN;
   if (a.upper_only && m0 > n0 + BN - 1) return;     // no element with row <= column in this block
+  // ... and in a block on the diagonal the wave whose 32 WMT x 32 WNT corner lies below it (one of four in a
+  // square block) only helps with the staging: no MFMAs, no stores
+  const bool dead = a.upper_only && m0 + wm * WMT * 32 > n0 + (wn * WNT + WNT) * 32 - 1;
   f32x16 acc[WMT][WNT];
 #pragma unroll
   for (int i = 0; i < WMT; ++i)
@@ -433,6 +436,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
     constexpr int p = decltype(par)::value;            // ci & 1
     const int buf = p;
     if (ci + 2 < nc) issue(ci + 2, rxx[p], ryy[p]);
+    if (!dead)
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 2) {
       float av[WMT], bv[WNT];
@@ -453,6 +457,7 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
     chunk(ci, std::integral_constant<int, 0>{});
     if (ci + 1 < nc) chunk(ci + 1, std::integral_constant<int, 1>{});
   }
+  if (dead) return;
   float* C = a.C + (size_t)b * a.sc;
 #pragma unroll
   for (int i = 0; i < WMT; ++i)
@@ -505,12 +510,13 @@ static void launch_lds(const BgemmArgs& a, hipStream_t s) {
   auto al4 = [](const void* p_, long st, int ld) {
     return p_ == nullptr || (((uintptr_t)p_ & 15) == 0 && (st & 3) == 0 && (ld & 3) == 0);
   };
-  const bool vec = WNT != 3 && (a.M & 3) == 0 && (a.N & 3) == 0 && al4(a.X, a.sx, a.ldx) &&
+  // (192-wide blocks stage 16 bytes per thread with 16-row stages only: 8 rows x 192 columns are 1.5 loads per thread)
+  const bool vec = (a.M & 3) == 0 && (a.N & 3) == 0 && al4(a.X, a.sx, a.ldx) &&
                    al4(a.Y, a.sy, a.ldy) && al4(a.K2 ? a.X2 : nullptr, a.sx2, a.ldx2) &&
                    al4(a.K2 ? a.Y2 : nullptr, a.sy2, a.ldy2) && al4(a.K3 ? a.X3 : nullptr, a.sx3, a.ldx3) &&
                    al4(a.K3 ? a.Y3 : nullptr, a.sy3, a.ldy3);
   if (vec)
-    hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT == 3 ? 2 : WNT, WNT == 2 ? GMPC_BG_KC_VEC22 : GMPC_BG_KC_VEC, true>), dim3((unsigned)(per * 8)),
+    hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT, WNT == 2 ? GMPC_BG_KC_VEC22 : GMPC_BG_KC_VEC, true>), dim3((unsigned)(per * 8)),
                        dim3(GMPC_THREADS), 0, s, a);
   else
     hipLaunchKernelGGL((k_bgemm_tn_lds<WMT, WNT, GMPC_BG_KC>), dim3((unsigned)(per * 8)), dim3(GMPC_THREADS), 0,
