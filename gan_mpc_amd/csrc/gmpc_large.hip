@@ -432,11 +432,15 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
   stage(0, rxx[0], ryy[0]);
   if (nc > 1) issue(1, rxx[1], ryy[1]);
   __syncthreads();
-  auto chunk = [&](int ci, auto par) __attribute__((always_inline)) {
+  // (the dead wave's chunk is a separate copy: a branch around the MFMAs inside the live one would split the basic
+  // block in which the compiler interleaves them with the loads and the LDS writes -- PA at the C4 shard 0.534 ->
+  // 0.564 ms)
+  auto chunk = [&](int ci, auto par, auto deadc) __attribute__((always_inline)) {
     constexpr int p = decltype(par)::value;            // ci & 1
+    constexpr bool DEAD = decltype(deadc)::value;
     const int buf = p;
     if (ci + 2 < nc) issue(ci + 2, rxx[p], ryy[p]);
-    if (!dead)
+    if constexpr (!DEAD)
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 2) {
       float av[WMT], bv[WNT];
@@ -453,11 +457,17 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
     if (ci + 1 < nc) stage(buf ^ 1, rxx[p ^ 1], ryy[p ^ 1]);
     __syncthreads();
   };
-  for (int ci = 0; ci < nc; ci += 2) {
-    chunk(ci, std::integral_constant<int, 0>{});
-    if (ci + 1 < nc) chunk(ci + 1, std::integral_constant<int, 1>{});
+  if (dead) {
+    for (int ci = 0; ci < nc; ci += 2) {
+      chunk(ci, std::integral_constant<int, 0>{}, std::true_type{});
+      if (ci + 1 < nc) chunk(ci + 1, std::integral_constant<int, 1>{}, std::true_type{});
+    }
+    return;
   }
-  if (dead) return;
+  for (int ci = 0; ci < nc; ci += 2) {
+    chunk(ci, std::integral_constant<int, 0>{}, std::false_type{});
+    if (ci + 1 < nc) chunk(ci + 1, std::integral_constant<int, 1>{}, std::false_type{});
+  }
   float* C = a.C + (size_t)b * a.sc;
 #pragma unroll
   for (int i = 0; i < WMT; ++i)
@@ -1420,6 +1430,9 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
     return g;
   };
   const int nt = (n + GMPC_PU_TILE - 1) / GMPC_PU_TILE;
+  // (read per pass, not once: the tests compare the two forms of the gain solve inside one process)
+  const char* sv_env = getenv("GMPC_BIG_SOLVE");
+  const bool solve_valu = sv_env != nullptr && strcmp(sv_env, "valu") == 0;
   for (int t = T - 1; t >= 0; --t) {
     const float* A = w.ABt;
     const float* Bm = w.ABt + n;
@@ -1475,7 +1488,6 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
     a.X = X; a.U = U; a.goal = goal; a.ng = w.ng; a.mpc_w = mpc_w; a.ABt = w.ABt; a.HG = w.HG; a.KV = w.KV; a.VK = w.VK;
     a.pvec = w.pvec; a.lam = w.lam; a.sbuf = w.sbuf; a.gn2 = w.gn2; a.active = active;
     a.K = K; a.k = k; a.grad = grad; a.adj = adj;
-    static const bool solve_valu = [] { const char* e = getenv("GMPC_BIG_SOLVE"); return e != nullptr && strcmp(e, "valu") == 0; }();
     a.solve_valu = solve_valu ? 1 : 0;
     hipLaunchKernelGGL(k_big_step, dim3(B), dim3(GMPC_THREADS), lds, s, a);
     // T1 = A^T (PA) + [K; V]^T [V; K], upper blocks only   (low-rank form: P + Vx Z + Z^T Vx^T)

@@ -41,6 +41,10 @@ SHAPES = {
     "regs-64": (6, 2, 5, 9, dict(dyn_hidden=(64, 64, 64), cost_hidden=(16,), cost_fout=3)),
     # n > 64: the step-major large-state backward pass (gmpc_large.hip)
     "big-70": (70, 7, 6, 5, dict(dyn_hidden=(128, 96), cost_hidden=(64,), cost_fout=12, out_scale=0.3)),
+    # control counts that land in the 8- and 16-block instantiations of the matrix-pipe gain solve with rows to
+    # spare (big_solve_mfma<8>: m = 30 of 32; <16>: m = 41 of 64)
+    "big-m30": (72, 30, 4, 3, dict(dyn_hidden=(96, 80), cost_hidden=(48,), cost_fout=8, out_scale=0.3)),
+    "big-m41": (90, 41, 3, 3, dict(dyn_hidden=(96, 80), cost_hidden=(48,), cost_fout=8, out_scale=0.3)),
     "c4-humanoid": (376, 17, 4, 3, dict(out_scale=0.3)),
     "c5-synthetic": (1024, 64, 3, 2, dict(out_scale=0.3)),
     # last hidden width h < n / 2: the large-state pass runs on the low-rank form A = I + W_L^T Vx^T (gmpc_large.hip)
@@ -339,6 +343,26 @@ def test_riccati_one_wave_form_and_linearize_event(monkeypatch):
         assert gu.rel_err(w[k], ref[k].cpu().numpy().astype(np.float64)) < 1e-3, k
 
 
+@pytest.mark.parametrize("name", ["big-70", "big-m30", "big-m41", "c4-humanoid", "c5-synthetic", "lowrank-2h"])
+def test_gain_solve_matrix_pipe_against_vector_form(name, monkeypatch):
+    """k_big_step's gain solve (trajax lqr_step: K, k = -(G + 1e-8 I)^-1 [H, h] by Cholesky substitutions): the
+    matrix-pipe form runs the same multiply-subtracts as the vector form kept behind GMPC_BIG_SOLVE=valu (two
+    interleaved accumulation chains per row instead of one) -- the gains agree far inside the gains' own fp32
+    forward error (1e-3 at these shapes), and the rest of the pass with them."""
+    pb, _, eng = _setup(name)
+    d = eng.to_dev
+    X, _ = eng.rollout_cost(d(pb["x0"]), d(pb["U"]), d(pb["goal"]))
+    outs = {}
+    for form in ("mfma", "valu"):
+        monkeypatch.setenv("GMPC_BIG_SOLVE", form)
+        o = eng.lqr_backward(X, d(pb["U"]), d(pb["goal"]), after_rollout=True)
+        outs[form] = {k: v.cpu().numpy().astype(np.float64) for k, v in o.items() if k in ("K", "k", "grad", "adjoints")}
+    for key in ("K", "k", "grad", "adjoints"):
+        a, b = outs["mfma"][key], outs["valu"][key]
+        assert np.isfinite(a).all()
+        assert gu.rel_err(a, b) < (2e-4 if key in ("K", "k") else 1e-5), (key, gu.rel_err(a, b))
+
+
 @pytest.mark.parametrize("name,loss_kind", [("trained-like", 0), ("trained-like", 1), ("big-70", 0),
                                             ("big-70", 1), ("c4-humanoid", 0), ("dynl-small", 0),
                                             ("dynl-small", 1), ("dynl-big", 0), ("dynl-big", 1),
@@ -490,7 +514,12 @@ def test_bad_calls_fail_loudly():
 
 
 @pytest.mark.parametrize("M,N,K,batch", [(376, 376, 376, 3), (17, 376, 376, 2), (376, 17, 17, 2),
-                                         (40, 70, 33, 5), (64, 1024, 129, 1)])
+                                         (40, 70, 33, 5), (64, 1024, 129, 1),
+                                         # the streaming thin-product kernel (k_bthin): wide X / wide Y, rows that
+                                         # are not 16-byte aligned, widths that are not multiples of 4 or 128, two
+                                         # thin strips, odd K
+                                         (376, 17, 376, 3), (17, 393, 376, 3), (130, 5, 33, 7), (7, 131, 35, 6),
+                                         (64, 1088, 200, 2), (1024, 64, 200, 2), (33, 257, 21, 4)])
 def test_bgemm_tn_matches_float64(M, N, K, batch):
     """building block of the large-state Riccati path: C = alpha X^T Y + beta C"""
     import ctypes as C
