@@ -87,6 +87,12 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
   commit();
   RW_SYNC();
 
+#ifdef GMPC_RICCATI_STAMPS
+  unsigned long long st_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tp_ = __builtin_readcyclecounter();
+#define RS_(i) { __builtin_amdgcn_s_waitcnt(0xc07f); const unsigned long long t_ = __builtin_readcyclecounter(); st_[i] += t_ - tp_; tp_ = t_; }
+#else
+#define RS_(i)
+#endif
   for (int t = T - 1; t >= 0; --t) {
     const size_t bt = (size_t)b * T + t;
     if (t > 0) prefetch(t - 1);
@@ -121,6 +127,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
         hv[j] = r + vp;                           // h = r_t + B^T p
       }
     }
+    RS_(0)
     // ---- W = P [A | B]
     f32x16_w acc;
 #pragma unroll
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
       const int row = (rg & 3) + 8 * (rg >> 2) + 4 * half;
       if (row < NR) Ws[row * LD + l31] = acc[rg];          // (rows n .. NR - 1 come out zero: P's padding)
     }
+    RS_(1)
     RW_SYNC();
     // ---- Z = [A | B]^T W
 #pragma unroll
@@ -151,6 +159,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
         else if (l31 < nm) Gr[(row - n) * m + l31 - n] = acc[rg];
       }
     }
+    RS_(2)
     RW_SYNC();
     // ---- G = sym(R + G_r), Cholesky of G + delta I, [K k] = -(G + delta I)^-1 [H h]
     if (lane < m * m) {
@@ -164,6 +173,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
       G[lane] = (Gp[lane] + Gp[j * m + i]) * 0.5f;
     }
     RW_SYNC();
+    RS_(3)
     if (lane == 0) {
       float Lr[m][m];
 #pragma unroll
@@ -186,6 +196,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
 #pragma unroll
         for (int j = 0; j <= i; ++j) Lc[i * m + j] = Lr[i][j];
     }
+    RS_(4)
     RW_SYNC();
     if (lane <= n) {
       const int c = lane;
@@ -211,6 +222,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
 #pragma unroll
       for (int i = 0; i < m; ++i) Kk[i * LD + c] = -y[i];      // column n: k_t
     }
+    RS_(5)
     RW_SYNC();
     // ---- outputs K_t, k_t; H + G K; the stacked operands [K; V], [V; K]
     for (int e = lane; e < m * n; e += 64) {
@@ -227,6 +239,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
       VKs[i * LD + j] = vv;  VKs[(m + i) * LD + j] = kij;
     }
     if (a.k && lane < m) a.k[bt * m + lane] = Kk[lane * LD + n];
+    RS_(6)
     RW_SYNC();
     // ---- S = A^T P A + K^T V + V^T K  (the accumulator still holds Z), P = Q_t + sym(S)
 #pragma unroll
@@ -249,6 +262,7 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
       }
       pn = ((qv[lane] + Ap[lane]) + v1) + v2;
     }
+    RS_(7)
     RW_SYNC();
     for (int e = lane; e < n * n; e += 64) {
       const int i = e / n, j = e - i * n;
@@ -261,10 +275,17 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
       lam[lane] = ln;
       if (a.adj) a.adj[((size_t)b * (T + 1) + t) * n + lane] = ln;
     }
+    RS_(8)
     RW_SYNC();                               // (dv, uv, Xs of this step are dead)
     if (t > 0) commit();
     RW_SYNC();
+    RS_(9)
   }
+#ifdef GMPC_RICCATI_STAMPS
+  if (blockIdx.x == 0 && lane == 0)
+    printf("k_riccati_w cycles per step: scalars+vec %llu | W=P[AB] %llu | Z %llu | G sym %llu | chol %llu | solve %llu | outputs %llu | S mfma+p %llu | P update %llu | commit %llu\n",
+           st_[0] / T, st_[1] / T, st_[2] / T, st_[3] / T, st_[4] / T, st_[5] / T, st_[6] / T, st_[7] / T, st_[8] / T, st_[9] / T);
+#endif
 
   if (a.cont != nullptr) {
     float un2 = 0.f;
@@ -290,6 +311,308 @@ __global__ __launch_bounds__(64) void k_riccati_w(RiccatiArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two waves per trajectory (k_riccati_w2): the sweep is one dependent chain per step --
+//   W = P [A|B] -> Z = [A|B]^T W -> G -> Cholesky -> [K k] -> S = Z_xx + [K;V]^T [V;K] -> P
+// -- and a single wave also runs everything else of the step in that chain's program order: the stage-cost
+// scalars (a 17-term sum, two square roots, the reciprocals), q_t, r_t, the adjoint recursion lambda_t = q_t +
+// A_t^T lambda_{t+1} with the control gradient, A_t^T p and h = r_t + B_t^T p, the next step's operands coming in
+// from global memory (stamps: 3.0 k + 1.0 k of the 13.9 k cycles of a step).  None of that needs this step's P.
+// Wave 1 (the helper) does it one step AHEAD into double-buffered LDS; wave 0 (the chain) finds [A|B]_t, x - g, u,
+// the scalars and q_t ready at the top of step t and h, A^T p before its solve.  Two workgroup barriers per step
+// (LDS counter only: the helper's prefetch and the chain's K stores stay in flight across them).
+// Same arithmetic, operation for operation, as k_riccati_w: the results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+#define RW2_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int N_, int M_>
+__global__ __launch_bounds__(128) void k_riccati_w2(RiccatiArgs a) {
+  constexpr int n = N_, m = M_, nm = n + m, LD = 32;
+  constexpr int NR = (n + 1) & ~1;
+  constexpr int KP = NR / 2;
+  static_assert(nm <= 32 && m <= 8 && n >= m, "one 32 x 32 tile");
+  __shared__ float Xs[2][NR * LD];                       // [A | B] of step t in buffer t & 1 (helper -> chain)
+  __shared__ float Ps[NR * LD], Ws[NR * LD], Ss[n * LD];
+  __shared__ float KVs[2 * m * LD], VKs[2 * m * LD], Hm[m * LD], HGK[m * LD], Kk[m * LD];
+  __shared__ float Gr[m * m], Gp[m * m], G[m * m], Lc[m * m];
+  __shared__ float dvb[2][LD], qvb[2][LD], uvb[2][8], rvb[2][8], scal[2][4];   // helper -> chain, buffer t & 1
+  __shared__ float pv[LD], lam[LD], Ap[LD], hv[8];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.x, T = a.T;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]);
+  const float al = GMPC_ALPHA;
+  const float delta = 1e-8f;
+  const int ng = a.ng > 0 ? a.ng : n;
+
+  for (int e = tid; e < 2 * NR * LD; e += 128) (&Xs[0][0])[e] = 0.f;
+  for (int e = tid; e < NR * LD; e += 128) { Ps[e] = 0.f; Ws[e] = 0.f; }
+  for (int e = tid; e < 2 * m * LD; e += 128) { KVs[e] = 0.f; VKs[e] = 0.f; }
+  RW2_BARRIER();
+
+  if (wave == 1) {
+    // ================= helper =================
+    constexpr int PFN = (n * nm + 63) / 64;
+    float pf_ab[PFN];
+    float pf_d = 0.f, pf_u = 0.f;
+    float gn2 = 0.f;
+    auto prefetch = [&](int tp) {
+      const size_t btp = (size_t)b * T + tp;
+#pragma unroll
+      for (int r = 0; r < PFN; ++r) {
+        const int e = lane + r * 64;
+        pf_ab[r] = e < n * nm ? a.AB[btp * n * nm + e] : 0.f;
+      }
+      if (lane < n)
+        pf_d = lane < ng ? a.X[((size_t)b * (T + 1) + tp) * n + lane] - a.goal[((size_t)b * (T + 1) + tp) * ng + lane]
+                         : 0.f;
+      if (lane < m) pf_u = a.U[btp * m + lane];
+    };
+    // everything of step tp that needs neither P nor p: operands into buffer tp & 1, scalars, q, r, the adjoint
+    auto prepare = [&](int tp) {
+      const int bf = tp & 1;
+      float* X_ = Xs[bf];
+#pragma unroll
+      for (int r = 0; r < PFN; ++r) {
+        const int e = lane + r * 64;
+        if (e < n * nm) X_[(e / nm) * LD + e % nm] = pf_ab[r];
+      }
+      if (lane < n) dvb[bf][lane] = pf_d;
+      if (lane < m) uvb[bf][lane] = pf_u;
+      RW_SYNC();
+      if (tp > 0) prefetch(tp - 1);
+      const float* dv = dvb[bf];
+      const float* uv = uvb[bf];
+      float dd = 0.f, uu = 0.f;
+#pragma unroll
+      for (int i = 0; i < n; ++i) dd = fmaf(dv[i], dv[i], dd);
+#pragma unroll
+      for (int j = 0; j < m; ++j) uu = fmaf(uv[j], uv[j], uu);
+      const float s = sqrtf(dd + al * al), su = sqrtf(uu + al * al);
+      const float is = 1.f / s, is3 = is * is * is, isu = 1.f / su, isu3 = isu * isu * isu;
+      if (lane == 0) { scal[bf][0] = is; scal[bf][1] = is3; scal[bf][2] = isu; scal[bf][3] = isu3; }
+      const size_t bt = (size_t)b * T + tp;
+      float ln = 0.f;
+      if (lane < nm) {
+        float vl = 0.f;
+#pragma unroll
+        for (int k = 0; k < n; ++k) vl = fmaf(X_[k * LD + lane], lam[k], vl);
+        if (lane < n) {
+          const float q = w1 * dv[lane] * is;
+          qvb[bf][lane] = q;
+          ln = q + vl;                               // lam_t = q_t + A^T lam
+        } else {
+          const int j = lane - n;
+          const float r = w0 * uv[j] * isu;
+          rvb[bf][j] = r;
+          const float g = r + vl;                    // g_t = r_t + B^T lam
+          gn2 = fmaf(g, g, gn2);
+          if (a.grad) a.grad[bt * m + j] = g;
+        }
+      }
+      RW_SYNC();                                     // (every lane has read lam)
+      if (lane < n) {
+        lam[lane] = ln;
+        if (a.adj) a.adj[((size_t)b * (T + 1) + tp) * n + lane] = ln;
+      }
+      RW_SYNC();
+    };
+    if (lane < n) {
+      const float q = a.qT[(size_t)b * n + lane];
+      pv[lane] = q;
+      lam[lane] = q;
+      if (a.adj) a.adj[((size_t)b * (T + 1) + T) * n + lane] = q;
+    }
+    RW_SYNC();
+    prefetch(T - 1);
+    prepare(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+      RW2_BARRIER();                                 // S_t: p_{t+1} is in pv
+      const int bf = t & 1;
+      if (lane < nm) {
+        float vp = 0.f;
+#pragma unroll
+        for (int k = 0; k < n; ++k) vp = fmaf(Xs[bf][k * LD + lane], pv[k], vp);
+        if (lane < n) Ap[lane] = vp;                 // A^T p
+        else hv[lane - n] = rvb[bf][lane - n] + vp;  // h = r_t + B^T p
+      }
+      RW2_BARRIER();                                 // V_t: h, A^T p are there for the chain's solve
+      if (t > 0) prepare(t - 1);
+    }
+    if (a.cont != nullptr) {
+      float un2 = 0.f;
+      for (int e = lane; e < T * m; e += 64) {
+        const float u = a.U[(size_t)b * T * m + e];
+        un2 = fmaf(u, u, un2);
+      }
+      gn2 = wave_sum(gn2);
+      un2 = wave_sum(un2);
+      if (lane == 0) {
+        float gn = sqrtf(gn2);
+        if (isnan(gn)) gn = INFINITY;
+        const float aobj = fabsf(a.obj[b]) + 1.0f;
+        const float un = sqrtf(un2) + 1.0f;
+        const bool progressing = (a.obj_step[b] > a.opts.obj_step_threshold * aobj) &&
+                                 (a.U_step[b] > a.opts.inputs_step_threshold * un);
+        const bool potential = (gn > a.opts.grad_norm_threshold) &&
+                               (gn > a.opts.relative_grad_norm_threshold * aobj);
+        const bool go = (a.iters[b] < a.opts.maxiter) && progressing && potential &&
+                        (a.alpha[b] > a.opts.alpha_min);
+        a.cont[b] = go ? 1 : 0;
+      }
+    }
+    return;
+  }
+
+  // ================= the chain =================
+  for (int e = lane; e < n * n; e += 64) Ps[(e / n) * LD + e % n] = a.QT[(size_t)b * n * n + e];
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t bt = (size_t)b * T + t;
+    const int bf = t & 1;
+    RW2_BARRIER();                                   // S_t: [A | B]_t, x - g, u, scalars, q_t are in buffer bf
+    const float* X_ = Xs[bf];
+    const float* dv = dvb[bf];
+    const float* uv = uvb[bf];
+    const float is = scal[bf][0], is3 = scal[bf][1], isu = scal[bf][2], isu3 = scal[bf][3];
+    // ---- W = P [A | B]
+    f32x16_w acc;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ps[(2 * kk + half) * LD + l31], X_[(2 * kk + half) * LD + l31], acc,
+                                                 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int row = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+      if (row < NR) Ws[row * LD + l31] = acc[rg];
+    }
+    RW_SYNC();
+    // ---- Z = [A | B]^T W
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < KP; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(X_[(2 * kk + half) * LD + l31], Ws[(2 * kk + half) * LD + l31], acc,
+                                                 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int row = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+      if (row >= n && row < nm) {
+        if (l31 < n) Hm[(row - n) * LD + l31] = acc[rg];
+        else if (l31 < nm) Gr[(row - n) * m + l31 - n] = acc[rg];
+      }
+    }
+    RW_SYNC();
+    // ---- G = sym(R + G_r), Cholesky of G + delta I
+    if (lane < m * m) {
+      const int i = lane / m, j = lane - i * m;
+      const float Rij = w0 * ((i == j ? isu : 0.f) - uv[i] * uv[j] * isu3);
+      Gp[lane] = Rij + Gr[lane];
+    }
+    RW_SYNC();
+    if (lane < m * m) {
+      const int i = lane / m, j = lane - i * m;
+      G[lane] = (Gp[lane] + Gp[j * m + i]) * 0.5f;
+    }
+    RW_SYNC();
+    if (lane == 0) {
+      float Lr[m][m];
+#pragma unroll
+      for (int j = 0; j < m; ++j) {
+        float sdiag = G[j * m + j] + delta;
+#pragma unroll
+        for (int k = 0; k < j; ++k) sdiag -= Lr[j][k] * Lr[j][k];
+        const float di = 1.0f / sqrtf(sdiag);
+        Lr[j][j] = di;
+#pragma unroll
+        for (int i = j + 1; i < m; ++i) {
+          float v = G[i * m + j];
+#pragma unroll
+          for (int k = 0; k < j; ++k) v -= Lr[i][k] * Lr[j][k];
+          Lr[i][j] = v * di;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < m; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Lc[i * m + j] = Lr[i][j];
+    }
+    RW2_BARRIER();                                   // V_t: h and A^T p have arrived
+    // ---- [K k] = -(G + delta I)^-1 [H h]
+    if (lane <= n) {
+      const int c = lane;
+      float Lr[m][m], y[m];
+#pragma unroll
+      for (int i = 0; i < m; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) Lr[i][j] = Lc[i * m + j];
+#pragma unroll
+      for (int i = 0; i < m; ++i) {
+        float v = c < n ? Hm[i * LD + c] : hv[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) v -= Lr[i][k] * y[k];
+        y[i] = v * Lr[i][i];
+      }
+#pragma unroll
+      for (int i = m - 1; i >= 0; --i) {
+        float v = y[i];
+#pragma unroll
+        for (int k = i + 1; k < m; ++k) v -= Lr[k][i] * y[k];
+        y[i] = v * Lr[i][i];
+      }
+#pragma unroll
+      for (int i = 0; i < m; ++i) Kk[i * LD + c] = -y[i];
+    }
+    RW_SYNC();
+    // ---- outputs K_t, k_t; H + G K; the stacked operands [K; V], [V; K]
+    for (int e = lane; e < m * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const float kij = Kk[i * LD + j];
+      if (a.K) a.K[bt * m * n + e] = kij;
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < m; ++k) v = fmaf(G[i * m + k], Kk[k * LD + j], v);
+      const float h = Hm[i * LD + j];
+      HGK[i * LD + j] = h + v;
+      const float vv = fmaf(0.5f, v, h);
+      KVs[i * LD + j] = kij; KVs[(m + i) * LD + j] = vv;
+      VKs[i * LD + j] = vv;  VKs[(m + i) * LD + j] = kij;
+    }
+    if (a.k && lane < m) a.k[bt * m + lane] = Kk[lane * LD + n];
+    RW_SYNC();
+    // ---- S = A^T P A + K^T V + V^T K, P = Q_t + sym(S)
+#pragma unroll
+    for (int kk = 0; kk < m; ++kk)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(KVs[(2 * kk + half) * LD + l31], VKs[(2 * kk + half) * LD + l31], acc,
+                                                 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) {
+      const int row = (rg & 3) + 8 * (rg >> 2) + 4 * half;
+      if (row < n) Ss[row * LD + l31] = acc[rg];
+    }
+    // p = q + A^T p + (H + G K)^T k + K^T h
+    float pn = 0.f;
+    if (lane < n) {
+      float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < m; ++k) {
+        v1 = fmaf(HGK[k * LD + lane], Kk[k * LD + n], v1);
+        v2 = fmaf(Kk[k * LD + lane], hv[k], v2);
+      }
+      pn = ((qvb[bf][lane] + Ap[lane]) + v1) + v2;
+    }
+    RW_SYNC();
+    for (int e = lane; e < n * n; e += 64) {
+      const int i = e / n, j = e - i * n;
+      const float Qij = w1 * ((i == j && i < ng ? is : 0.f) - dv[i] * dv[j] * is3);
+      Ps[i * LD + j] = Qij + (Ss[i * LD + j] + Ss[j * LD + i]) * 0.5f;
+    }
+    if (lane < n) pv[lane] = pn;
+    RW_SYNC();
+  }
+}
+
 // the shapes the one-wave form is instantiated for (mode 0 only); GMPC_RICCATI=valu keeps k_riccati
 bool gmpc_riccati_w_shape(const RiccatiArgs& a) {
   const char* e = getenv("GMPC_RICCATI");
@@ -297,5 +620,7 @@ bool gmpc_riccati_w_shape(const RiccatiArgs& a) {
   return a.mode == 0 && a.Phi == nullptr && a.n == 17 && a.m == 6;
 }
 void gmpc_launch_riccati_w(const RiccatiArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((k_riccati_w<17, 6>), dim3(a.B), dim3(64), 0, s, a);
+  const char* e = getenv("GMPC_RICCATI_W");          // "1": the one-wave form (A/B timing; read per call: tests)
+  if (e != nullptr && e[0] == '1') hipLaunchKernelGGL((k_riccati_w<17, 6>), dim3(a.B), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((k_riccati_w2<17, 6>), dim3(a.B), dim3(128), 0, s, a);
 }
