@@ -375,6 +375,30 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
         B_(Sb, B * hmax * hl + pad);
       }
     }
+    // one-step-ahead Jacobians on a side stream (MLP dynamics; GMPC_BIG_PIPELINE=0: one stream, one buffer)
+    {
+      const char* e = getenv("GMPC_BIG_PIPELINE");
+      // (the low-rank form supports it too -- Vt2 / Sm -- and gains nothing: its factor GEMMs and k_big_step slow
+      // each other down by what the overlap saves, C5 1.980 vs 1.984 s; GMPC_BIG_PIPELINE=2 turns it on there)
+      const bool lr_too = e != nullptr && e[0] == '2';
+      if (!c->dynl && !(e != nullptr && e[0] == '0') && (c->bw.h == 0 || lr_too)) {
+        if (c->bw.h > 0) {
+          const size_t hl = c->bw.h;
+          B_(Vt2, B * hl * nm + pad);
+          B_(Sm, B * hl * hl + pad);
+        } else {
+          B_(ABt2, B * n * nm + pad);
+        }
+        if (!rc) {
+          bool ok = hipStreamCreateWithFlags(&c->bw.side, hipStreamNonBlocking) == hipSuccess;
+          ok = ok && hipEventCreateWithFlags(&c->bw.ev_start, hipEventDisableTiming) == hipSuccess;
+          for (int i = 0; i < 2 && ok; ++i)
+            ok = hipEventCreateWithFlags(&c->bw.ev_ready[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->bw.ev_free[i], hipEventDisableTiming) == hipSuccess;
+          if (!ok) rc = fail(GMPC_EHIP, "side stream / events of the large-state pass");
+        }
+      }
+    }
 #undef B_
     c->AB = c->bw.ABt;
   }
@@ -481,6 +505,12 @@ extern "C" int gmpc_destroy(gmpc_ctx* c) {
   if (c->hcont) {
     (void)hipHostFree(c->hcont);
     for (int i = 0; i < GMPC_POLL_DEPTH; ++i) (void)hipEventDestroy(c->poll_ev[i]);
+  }
+  if (c->bw.side) (void)hipStreamDestroy(c->bw.side);
+  if (c->bw.ev_start) (void)hipEventDestroy(c->bw.ev_start);
+  for (int i = 0; i < 2; ++i) {
+    if (c->bw.ev_ready[i]) (void)hipEventDestroy(c->bw.ev_ready[i]);
+    if (c->bw.ev_free[i]) (void)hipEventDestroy(c->bw.ev_free[i]);
   }
   for (void* p : c->allocs) (void)hipFree(p);
   delete c;

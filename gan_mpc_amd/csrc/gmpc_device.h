@@ -329,6 +329,12 @@ struct BigWork {
   int h = 0;             // 0: dense form
   float *Vt = nullptr, *W1b = nullptr, *W2b = nullptr, *Sa = nullptr, *Sb = nullptr;
   float* Phi = nullptr;  // [B][n+m][n+m] curvature of one step (LSTM dynamics, bilevel solve)
+  // one-step-ahead Jacobians (gmpc_big_backward): the step's [A | B] (dense form) or its factor V^T (low-rank form)
+  // does not depend on P, so step t - 1's is produced on a side stream while step t's products run; second copies
+  // of the buffers (step t uses copy t & 1; copy 0 is ABt / Vt), S of the low-rank form off the factor's scratch
+  float *ABt2 = nullptr, *Vt2 = nullptr, *Sm = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_start = nullptr, ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
 };
 
 // zero-padded weight copies read by the MFMA Jacobian chain (gmpc_linearize_mfma.hip)

@@ -1433,14 +1433,53 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
   // (read per pass, not once: the tests compare the two forms of the gain solve inside one process)
   const char* sv_env = getenv("GMPC_BIG_SOLVE");
   const bool solve_valu = sv_env != nullptr && strcmp(sv_env, "valu") == 0;
+  // One step ahead on a side stream: the Jacobians of a step ([A | B], or the factor V^T of the low-rank form) do
+  // not depend on P.  Step t's are produced into copy t & 1 of their buffer while step t + 1's products run on the
+  // caller's stream -- the Jacobian chain / the factor GEMMs fill the matrix pipe under k_big_step, k_big_pupdate,
+  // the thin products and the transposes, which leave it idle.  ev_ready[i]: copy i is written; ev_free[i]: the point of
+  // the caller's stream behind which copy i may be overwritten.
+  const bool pipe = w.side != nullptr && dl == nullptr && (lowrank ? w.Vt2 != nullptr : w.ABt2 != nullptr);
+  float* const ABc[2] = {w.ABt, pipe && !lowrank ? w.ABt2 : w.ABt};
+  float* const Vtc[2] = {w.Vt, pipe && lowrank ? w.Vt2 : w.Vt};
+  int rc_side = 0;
+  auto jacobians = [&](int t, hipStream_t st) {
+    if (lowrank) {
+      BigWork wv = w;
+      wv.Vt = Vtc[t & 1];
+      big_lowrank_factors(wv, B, dyn, masks, t, active, st);
+    } else if (gmpc_launch_linearize_regs(B, T, n, m, dyn, lp, masks, active, ABc[t & 1], T, t, st) != 0 &&
+               gmpc_launch_linearize_mfma(B, T, n, m, dyn, lp, masks, active, ABc[t & 1], T, t, st) != 0) {
+      rc_side = -1;
+    }
+  };
+  if (pipe) {
+    (void)hipEventRecord(w.ev_start, s);                 // the side stream starts behind the caller's earlier work
+    (void)hipStreamWaitEvent(w.side, w.ev_start, 0);
+    jacobians(T - 1, w.side);
+    (void)hipEventRecord(w.ev_ready[(T - 1) & 1], w.side);
+  }
   for (int t = T - 1; t >= 0; --t) {
-    const float* A = w.ABt;
-    const float* Bm = w.ABt + n;
+    const float* A = ABc[t & 1];
+    const float* Bm = ABc[t & 1] + n;
+    const float* Vt_t = Vtc[t & 1];
     const long shn = (long)h * n, shnm = (long)h * nm;
     const float* WLT = lowrank ? dyn.WT[dyn.L - 1] : nullptr;     // [n][h]: W_L^T, the TN left operand of W_L (.)
+    // step t - 1's Jacobians start when step t reaches its stretch of kernels that leave the matrix pipe idle (the
+    // thin products, k_big_step, ...): started at the top of the step they only shared the pipe with the step's
+    // first big GEMM, both at half speed (kernel trace: linearize 0.66 ms beside PA 1.04 ms, then 0.36 ms of thin
+    // products and k_big_step alone)
+    auto start_next = [&]() {
+      if (!pipe || t == 0) return;
+      (void)hipEventRecord(w.ev_free[(t - 1) & 1], s);      // (the copy's last reader was step t + 1; this point is later)
+      (void)hipStreamWaitEvent(w.side, w.ev_free[(t - 1) & 1], 0);
+      jacobians(t - 1, w.side);
+      (void)hipEventRecord(w.ev_ready[(t - 1) & 1], w.side);
+    };
+    if (pipe) (void)hipStreamWaitEvent(s, w.ev_ready[t & 1], 0);
+    else if (dl == nullptr) jacobians(t, s);
+    if (rc_side != 0) return -1;
     if (lowrank) {
-      // the factors V_t^T, then the n^3 products through them (see big_lowrank_factors)
-      big_lowrank_factors(w, B, dyn, masks, t, active, s);
+      // the factors V_t^T (above), then the n^3 products through them (see big_lowrank_factors)
       // Y = W_L P, S = W_L P W_L^T = W_L Y^T, then with Z = Y + S Vx^T / 2:
       //     A^T P A = P + Vx Z + Z^T Vx^T            (T1 below: two K-segments of h rows, a third for K, V)
       //     [H | Gr] = B^T P [A | B] = Vu ([Y | 0] + S V^T) = Vu (2 [Z | S Vu^T / 2] - [Y | 0])
@@ -1450,29 +1489,28 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
       float* Yt = w.PAB;                                                                        // [n][h]
       hipLaunchKernelGGL(k_btranspose, dim3((n + 63) / 64, (h + 63) / 64, B), dim3(GMPC_THREADS), 0, s, h, n,
                          w.W1b, Yt, active);
-      float* S = w.Sa;                                                                          // [h][h]
+      float* S = pipe ? w.Sm : w.Sa;                          // [h][h] (Sa / Sb are the factor products' scratch)
       const long shh = (long)h * h;
       gmpc_launch_bgemm_tn(gemm(h, h, n, WLT, 0, h, Yt, shn, h, S, shh, h), s);                 // S = W_L Y^T
       // W2b = S V^T / 2 + [Y | 0] = [Z | S Vu^T / 2]   (S symmetric up to rounding: S^T V^T is the TN form)
-      BgemmArgs g2 = gemm(h, n, h, S, shh, h, w.Vt, shnm, nm, w.W2b, shnm, nm);
+      BgemmArgs g2 = gemm(h, n, h, S, shh, h, Vt_t, shnm, nm, w.W2b, shnm, nm);
       g2.alpha = 0.5f; g2.E = w.W1b; g2.se = shn; g2.lde = n; g2.En = n;
       gmpc_launch_bgemm_tn(g2, s);
-      BgemmArgs g3 = gemm(h, m, h, S, shh, h, w.Vt + n, shnm, nm, w.W2b + n, shnm, nm);
+      BgemmArgs g3 = gemm(h, m, h, S, shh, h, Vt_t + n, shnm, nm, w.W2b + n, shnm, nm);
       g3.alpha = 0.5f;
       gmpc_launch_bgemm_tn(g3, s);
-      BgemmArgs g4 = gemm(m, nm, h, w.Vt + n, shnm, nm, w.W2b, shnm, nm, w.HG, smnm, nm);       // 2 Vu W2b
+      BgemmArgs g4 = gemm(m, nm, h, Vt_t + n, shnm, nm, w.W2b, shnm, nm, w.HG, smnm, nm);       // 2 Vu W2b
       g4.alpha = 2.f;
       gmpc_launch_bgemm_tn(g4, s);
-      BgemmArgs g5 = gemm(m, n, h, w.Vt + n, shnm, nm, w.W1b, shn, n, w.HG, smnm, nm);          // - Vu [Y | 0]
+      BgemmArgs g5 = gemm(m, n, h, Vt_t + n, shnm, nm, w.W1b, shn, n, w.HG, smnm, nm);          // - Vu [Y | 0]
       g5.alpha = -1.f; g5.beta = 1.f;
       gmpc_launch_bgemm_tn(g5, s);
+      start_next();
     } else {
-    if (dl) {
-      gmpc_launch_dynl_jac(B, T, 1, t, *dl, X, U, active, w.ABt, s);
-    } else if (gmpc_launch_linearize_regs(B, T, n, m, dyn, lp, masks, active, w.ABt, T, t, s) != 0 &&
-               gmpc_launch_linearize_mfma(B, T, n, m, dyn, lp, masks, active, w.ABt, T, t, s) != 0) return -1;
+    if (dl) gmpc_launch_dynl_jac(B, T, 1, t, *dl, X, U, active, w.ABt, s);
     // [PA | PB] = P [A | B]   (P symmetric, so P = P^T is the "TN" left operand)
     gmpc_launch_bgemm_tn(gemm(n, n, n, w.P, snn, n, A, snm, nm, w.PAB, snm, nm), s);
+    start_next();
     gmpc_launch_bgemm_tn(gemm(n, m, n, w.P, snn, n, Bm, snm, nm, w.PAB + n, snm, nm), s);
     // [H | Gr] = B^T [PA | PB]
     gmpc_launch_bgemm_tn(gemm(m, nm, n, Bm, snm, nm, w.PAB, snm, nm, w.HG, smnm, nm), s);
@@ -1482,22 +1520,22 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
       gmpc_launch_add_phi(B, n, m, w.Phi, w.HG, nullptr, s);
     }
     BigStepArgs a;
-    a.Vt = lowrank ? w.Vt : nullptr; a.WL = lowrank ? dyn.W[dyn.L - 1] : nullptr; a.h = h;
+    a.Vt = lowrank ? Vt_t : nullptr; a.WL = lowrank ? dyn.W[dyn.L - 1] : nullptr; a.h = h;
     a.B = B; a.n = n; a.m = m; a.T = T; a.t = t;
     a.mode = lx != nullptr ? 1 : 0; a.lx = lx; a.Bvec = Bvec;
-    a.X = X; a.U = U; a.goal = goal; a.ng = w.ng; a.mpc_w = mpc_w; a.ABt = w.ABt; a.HG = w.HG; a.KV = w.KV; a.VK = w.VK;
+    a.X = X; a.U = U; a.goal = goal; a.ng = w.ng; a.mpc_w = mpc_w; a.ABt = A; a.HG = w.HG; a.KV = w.KV; a.VK = w.VK;
     a.pvec = w.pvec; a.lam = w.lam; a.sbuf = w.sbuf; a.gn2 = w.gn2; a.active = active;
     a.K = K; a.k = k; a.grad = grad; a.adj = adj;
     a.solve_valu = solve_valu ? 1 : 0;
     hipLaunchKernelGGL(k_big_step, dim3(B), dim3(GMPC_THREADS), lds, s, a);
     // T1 = A^T (PA) + [K; V]^T [V; K], upper blocks only   (low-rank form: P + Vx Z + Z^T Vx^T)
-    BgemmArgs g = lowrank ? gemm(n, n, h, w.Vt, shnm, nm, w.W2b, shnm, nm, w.T1, snn, n)
+    BgemmArgs g = lowrank ? gemm(n, n, h, Vt_t, shnm, nm, w.W2b, shnm, nm, w.T1, snn, n)
                           : gemm(n, n, n, A, snm, nm, w.PAB, snm, nm, w.T1, snn, n);
     g.X2 = w.KV; g.sx2 = 2 * smn; g.ldx2 = n;
     g.Y2 = w.VK; g.sy2 = 2 * smn; g.ldy2 = n; g.K2 = 2 * m;
     if (lowrank) {
       g.E = w.P; g.se = snn; g.lde = n; g.En = n;
-      g.X3 = w.W2b; g.sx3 = shnm; g.ldx3 = nm; g.Y3 = w.Vt; g.sy3 = shnm; g.ldy3 = nm; g.K3 = h;
+      g.X3 = w.W2b; g.sx3 = shnm; g.ldx3 = nm; g.Y3 = Vt_t; g.sy3 = shnm; g.ldy3 = nm; g.K3 = h;
     }
     static const bool full_t1 = getenv("GMPC_BIG_FULL_T1") != nullptr;   // A/B timing only
     g.upper_only = full_t1 ? 0 : 1;
