@@ -306,8 +306,8 @@ def main():
     import ctypes as C
     from gan_mpc_amd import _lib
 
-    # Two streams for the small-state workloads: the Riccati sweep there is one wavefront per trajectory
-    # (k_riccati_w: a quarter of the wave slots), the critic's kernels fill the rest; the Jacobian chain
+    # Two streams for the small-state workloads: the Riccati sweep there is two wavefronts per trajectory
+    # (k_riccati_w2: half of the wave slots, a quarter of the registers), the critic's kernels fill the rest; the Jacobian chain
     # (matrix-core-bound, all registers) always runs alone.  The large-state pipeline keeps one stream.
     side = torch.cuda.Stream() if (not args.no_overlap and n <= 64) else None
     lin_ev = None
