@@ -212,7 +212,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10,
+                    help="untimed steps before the timed window (the first ~5 steps of a process run 2-3 %% slow: 3 warm-up "
+                         "steps put them inside the first window, 1.72 against 1.68 ms per step)")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS),
                     help="c3 = the headline configuration; c4 / c5 = per-GPU shards of the large-state configs")
     ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (0: the workload's)")
