@@ -437,6 +437,9 @@ bool gmpc_launch_lstm_bwd2(int Bc, const CriticDesc& cd, const float* xseq, cons
 // act[row][k] * dscore[row] with dscore in column K: its weight and bias gradients are column sums (`plast`).
 // ---------------------------------------------------------------------------------------------------------------
 #define GMPC_HEAD2_LD 264     // leading dimension of plast: 256 products + dscore, padded to a multiple of 8
+#ifndef GMPC_HEAD_RING
+#define GMPC_HEAD_RING 3       // weight chunks of head_layer in flight + 1
+#endif
 
 // d[g] += sum_k img[g][k][.] (x) W[k][col] over Kred rows of W (leading dimension ldw).  The weights come through a
 // buffer resource that ends with the matrix: rows past Kred (the last 16-row chunk, the chunks requested ahead of
@@ -451,7 +454,9 @@ __device__ __forceinline__ void head_layer(const float* __restrict__ W, int ldw,
       const_cast<float*>(W), 0, __builtin_amdgcn_readfirstlane(Kred * ldw * (int)sizeof(float)), 0x00020000);
   const int voff = colok ? col * 4 : 0x7ffffff0;
   const int rowb = ldw * 4;
-  float w0[16], w1[16], w2[16], a0[G], a1[G], a2[G];
+  // ring of GMPC_HEAD_RING chunks: RING - 1 chunks (16 weight rows each) are on their way while one multiplies
+  constexpr int RING = GMPC_HEAD_RING;
+  float wq[RING][16], aq[RING][G];
   auto loadw = [&](int c, float (&dst)[16]) {
     const int base = voff + 16 * c * rowb;
 #pragma unroll
@@ -470,21 +475,17 @@ __device__ __forceinline__ void head_layer(const float* __restrict__ W, int ldw,
       for (int g = 0; g < G; ++g) rw_mfma<kk>(d[g], a[g], w[kk]);
     });
   };
-  loadw(0, w0); loada(0, a0);
-  loadw(1, w1); loada(1, a1);
-  for (int c = 0; c < chunks; c += 3) {
-    loadw(c + 2, w2); loada(c + 2, a2);
-    __builtin_amdgcn_sched_barrier(0);
-    run(a0, w0);
-    __builtin_amdgcn_sched_barrier(0);
-    loadw(c + 3, w0); loada(c + 3, a0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 1 < chunks) run(a1, w1);
-    __builtin_amdgcn_sched_barrier(0);
-    loadw(c + 4, w1); loada(c + 4, a1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (c + 2 < chunks) run(a2, w2);
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i + 1 < RING; ++i) { loadw(i, wq[i]); loada(i, aq[i]); }
+  for (int c = 0; c < chunks; c += RING) {
+    rw_static_for<RING>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int i = decltype(ic)::value;
+      constexpr int nx = (i + RING - 1) % RING;
+      loadw(c + i + RING - 1, wq[nx]); loada(c + i + RING - 1, aq[nx]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + i < chunks) run(aq[i], wq[i]);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
 }
 
