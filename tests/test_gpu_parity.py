@@ -341,6 +341,14 @@ def test_riccati_one_wave_form_and_linearize_event(monkeypatch):
         assert gu.rel_err(w[k], ref[k].cpu().numpy().astype(np.float64)) < 1e-5, k
     for k in ("K", "k"):       # gains: two fp32 routes through cond(G) ~ 1e4
         assert gu.rel_err(w[k], ref[k].cpu().numpy().astype(np.float64)) < 1e-3, k
+    # the two-wave sweep (k_riccati_w2, the default) runs the one-wave kernel's arithmetic operation for operation
+    # -- the helper wave only takes over what does not depend on the step's P: the outputs are bit-identical,
+    # also with trajectories switched off
+    monkeypatch.delenv("GMPC_RICCATI")
+    monkeypatch.setenv("GMPC_RICCATI_W", "1")
+    one = eng.lqr_backward(Xd, d(pb["U"]), d(pb["goal"]), after_rollout=True)
+    for k in ("K", "k", "grad", "adjoints"):
+        np.testing.assert_array_equal(w[k], one[k].cpu().numpy(), err_msg=k)
 
 
 @pytest.mark.parametrize("name", ["big-70", "big-m30", "big-m41", "c4-humanoid", "c5-synthetic", "lowrank-2h"])
