@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgan_mpc_step.so")
+# GMPC_STEP_LIB: another build of the same library (the sanitizer build of tests/test_oracle_c.py)
+LIB_PATH = os.environ.get("GMPC_STEP_LIB") or os.path.join(_HERE, "libgan_mpc_step.so")
 _lib = None
 _F = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _I = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")

@@ -67,3 +67,32 @@ def test_c_adam_clip_matches_numpy_oracle():
         oc.adam_clip(p, g, m, v, 0.5, step, 1e-3)
         p64, m64, v64 = orc.adam_clip_step(p64, 0.5 * g.astype(np.float64), m64, v64, step, 1e-3)
         assert _rel(p, p64) < 1e-6 and _rel(m, m64) < 1e-6 and _rel(v, v64) < 1e-6
+
+
+def test_c_step_under_address_and_ub_sanitizers(tmp_path):
+    """The C restatement built with -fsanitize=address,undefined and driven through the tests above in a child
+    process (the sanitizer runtime has to be preloaded before Python): no out-of-bounds access, no undefined
+    behaviour on the seeded shapes.  (GPU sanitizers are not available on the pool; this is the CPU side.)"""
+    import shutil
+    import subprocess
+    import sys
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    asan = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not asan or not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = str(tmp_path / "libgan_mpc_step_asan.so")
+    subprocess.check_call([gcc, "-O1", "-g", "-fPIC", "-fopenmp", "-mavx2", "-mfma", "-std=c11", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-shared", "-o", lib,
+                           os.path.join(root, "oracle", "gan_mpc_step.c"), "-lm"])
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", OMP_NUM_THREADS="2",
+               GMPC_STEP_LIB=lib)
+    code = ("import sys, gan_mpc_step_c as oc; assert oc.LIB_PATH.endswith('_asan.so'), oc.LIB_PATH; "
+            "import pytest; sys.exit(pytest.main(['-x', '-q', '-p', 'no:cacheprovider', %r, '-k', 'not sanitizers']))"
+            % os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, PYTHONPATH=os.path.join(root, "oracle")),
+                       capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
