@@ -253,6 +253,10 @@ struct gmpc_ctx {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[GMPC_PROF_SLOTS];
   const char* lin_kernel = "";      // kernel the last Jacobian chain ran on (gmpc_profile_kernel_name)
   hipEvent_t lin_event = nullptr;   // caller's event, recorded after the Jacobian chain (gmpc_set_linearize_event)
+  // the critic's head weight gradients run beside the BPTT sweep (critic_forward_backward): a context-owned side
+  // stream forked after k_head2 and joined behind the sweep
+  hipStream_t crit_side = nullptr;
+  hipEvent_t crit_fork = nullptr, crit_join = nullptr;
 };
 
 // RAII bracket: records a start/stop event pair around one kernel launch when profiling is on
@@ -506,6 +510,9 @@ extern "C" int gmpc_destroy(gmpc_ctx* c) {
     (void)hipHostFree(c->hcont);
     for (int i = 0; i < GMPC_POLL_DEPTH; ++i) (void)hipEventDestroy(c->poll_ev[i]);
   }
+  if (c->crit_side) (void)hipStreamDestroy(c->crit_side);
+  if (c->crit_fork) (void)hipEventDestroy(c->crit_fork);
+  if (c->crit_join) (void)hipEventDestroy(c->crit_join);
   if (c->bw.side) (void)hipStreamDestroy(c->bw.side);
   if (c->bw.ev_start) (void)hipEventDestroy(c->bw.ev_start);
   for (int i = 0; i < 2; ++i) {
@@ -840,7 +847,7 @@ static int bind_critic(gmpc_ctx* c, const float* critic, CriticDesc& cd, hipStre
 
 static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const float* label,
                                    const float* critic, int loss_kind, float* dxseq, bool want_wgrad,
-                                   float* grad_sum, hipStream_t s) {
+                                   float* grad_sum, hipStream_t s, float* loss_sum = nullptr) {
   CriticDesc cd;
   TRY(bind_critic(c, critic, cd, s));
   const gmpc_shape& sh = c->sh;
@@ -881,6 +888,25 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     gmpc_launch_head2(Bc, cd, loss_kind, c->hT, label, c->cscore, c->closs, c->hacts, c->hdels, c->plast, c->dhT,
                       c->hstride, s);
   }
+  // The head's weight gradients (k_wgrad_batch + its reduction) and the loss sum need k_head2's outputs only; the
+  // BPTT sweep after it is a latency chain at one wave per SIMD.  Forked onto a side stream they run under the
+  // sweep instead of behind it (GMPC_CRITIC_SIDE=0: one stream).
+  hipStream_t sw = s;
+  bool forked = false;
+  if (gen2 && want_wgrad) {
+    const char* e = getenv("GMPC_CRITIC_SIDE");
+    if (!(e != nullptr && e[0] == '0')) {
+      if (!c->crit_side) {
+        HIP_TRY(hipStreamCreateWithFlags(&c->crit_side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->crit_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->crit_join, hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(c->crit_fork, s));
+      HIP_TRY(hipStreamWaitEvent(c->crit_side, c->crit_fork, 0));
+      sw = c->crit_side;
+      forked = true;
+    }
+  }
   float* gWx0 = grad_sum;
   if (gen2 && (dxseq || want_wgrad)) {
     // backward sweep with the LSTM weight gradients accumulated in registers (no dz in memory), then the
@@ -902,7 +928,7 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     }
   }
   if (want_wgrad) {
-    ProfScope ps(c, PROF_WGRAD, s);
+    ProfScope ps(c, PROF_WGRAD, sw);
     const int rows = Bc * T1, G4 = 4 * F;
     float* gWx = grad_sum;
     float* gWh = gWx + (long)n * G4;
@@ -944,7 +970,7 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
       aoff += M;
       doff += N;
     }
-    if (np > 0 && !gmpc_launch_wgrad_batch(pr, np, c->wpart, c->wpart_floats, s)) {
+    if (np > 0 && !gmpc_launch_wgrad_batch(pr, np, c->wpart, c->wpart_floats, sw)) {
       for (int i = 0; i < np; ++i)
         single[ns++] = Single{pr[i].rows, pr[i].M, pr[i].N, pr[i].A, pr[i].lda, pr[i].B, pr[i].ldb, pr[i].C,
                               pr[i].colsum, pr[i].cs_rows};
@@ -952,12 +978,17 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     // the rest one by one, after the batch (they reuse the partial-sum buffer: stream order)
     for (int i = 0; i < ns; ++i) {
       if (single[i].M == 0)
-        gmpc_launch_colsum(single[i].csr, single[i].N, single[i].Bm, single[i].ldb, single[i].cs, c->wpart, s);
+        gmpc_launch_colsum(single[i].csr, single[i].N, single[i].Bm, single[i].ldb, single[i].cs, c->wpart, sw);
       else
         gmpc_launch_wgrad(single[i].r, single[i].M, single[i].N, single[i].A, single[i].lda, single[i].Bm,
-                          single[i].ldb, single[i].Cw, single[i].cs, single[i].csr, c->wpart, 256, s,
+                          single[i].ldb, single[i].Cw, single[i].cs, single[i].csr, c->wpart, 256, sw,
                           c->wpart_floats, true);
     }
+  }
+  if (loss_sum) gmpc_launch_sum(Bc, c->closs, loss_sum, 0, sw);
+  if (forked) {
+    HIP_TRY(hipEventRecord(c->crit_join, sw));
+    HIP_TRY(hipStreamWaitEvent(s, c->crit_join, 0));
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -972,8 +1003,7 @@ extern "C" int gmpc_critic_loss_grad(gmpc_ctx* c, int Bc, const float* xseq, con
   HIP_TRY(hipSetDevice(c->device));
   (void)hipGetLastError();   // clean slate (see check_call)
   hipStream_t s = static_cast<hipStream_t>(stream);
-  TRY(critic_forward_backward(c, Bc, xseq, label, critic, 0, nullptr, true, grad_sum, s));
-  gmpc_launch_sum(Bc, c->closs, loss_sum, 0, s);
+  TRY(critic_forward_backward(c, Bc, xseq, label, critic, 0, nullptr, true, grad_sum, s, loss_sum));
   HIP_TRY(hipGetLastError());
   return 0;
 }

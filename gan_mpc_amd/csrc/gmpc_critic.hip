@@ -436,12 +436,22 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_sqsum_part(long count, const f
 
 // optax clip_by_global_norm + adam (gan/runner.py:58): g <- g*scale; if !(norm < max_norm)
 // g <- g / norm * max_norm; m,v update; p += -lr * mhat / (sqrt(vhat) + eps)
-__global__ void k_adam(long count, float* p, const float* g, float* m, float* v, float scale,
-                       const float* sqsum, float max_norm, float lr, float b1, float b2, float omb1,
-                       float omb2, float eps, float bc1, float bc2) {
+// `sqpart`: the 256 partial sums of k_sqsum_part; every block adds them up itself -- the tree of k_sum over the same
+// values, so the norm has the bits it had when a k_sum launch stood between the two kernels (one launch and one
+// dependent kernel boundary less on the tail of every step)
+__global__ __launch_bounds__(256) void k_adam(long count, float* p, const float* g, float* m, float* v, float scale,
+                                              const float* sqpart, float max_norm, float lr, float b1, float b2,
+                                              float omb1, float omb2, float eps, float bc1, float bc2) {
+  __shared__ float sh[256];
+  sh[threadIdx.x] = sqpart[threadIdx.x];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= count) return;
-  const float gn = sqrtf(sqsum[0]);
+  const float gn = sqrtf(sh[0]);
   float x = g[e] * scale;
   if (!(gn < max_norm)) x = x / gn * max_norm;
   const float mn = b1 * m[e] + omb1 * x;
@@ -598,10 +608,9 @@ void gmpc_launch_adam(long count, float* p, const float* g, float* m, float* v, 
                       float* scratch /* >= 257 floats */, hipStream_t s) {
   const int nb = 256;
   hipLaunchKernelGGL(k_sqsum_part, dim3(nb), dim3(GMPC_THREADS), 0, s, count, g, scale, scratch + 1);
-  hipLaunchKernelGGL(k_sum, dim3(1), dim3(1024), 0, s, nb, scratch + 1, scratch, 0);
   const float bc1 = (float)(1.0 - pow(b1, (double)step)), bc2 = (float)(1.0 - pow(b2, (double)step));
   hipLaunchKernelGGL(k_adam, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, count, p, g, m, v,
-                     scale, scratch, (float)max_norm, (float)lr, (float)b1, (float)b2,
+                     scale, scratch + 1, (float)max_norm, (float)lr, (float)b1, (float)b2,
                      (float)(1.0 - b1), (float)(1.0 - b2), (float)eps, bc1, bc2);
 }
 
