@@ -256,7 +256,7 @@ struct gmpc_ctx {
   // the critic's head weight gradients run beside the BPTT sweep (critic_forward_backward): a context-owned side
   // stream forked after k_head2 and joined behind the sweep
   hipStream_t crit_side = nullptr;
-  hipEvent_t crit_fork = nullptr, crit_join = nullptr;
+  hipEvent_t crit_fork = nullptr, crit_join = nullptr, crit_tr = nullptr;
 };
 
 // RAII bracket: records a start/stop event pair around one kernel launch when profiling is on
@@ -513,6 +513,7 @@ extern "C" int gmpc_destroy(gmpc_ctx* c) {
   if (c->crit_side) (void)hipStreamDestroy(c->crit_side);
   if (c->crit_fork) (void)hipEventDestroy(c->crit_fork);
   if (c->crit_join) (void)hipEventDestroy(c->crit_join);
+  if (c->crit_tr) (void)hipEventDestroy(c->crit_tr);
   if (c->bw.side) (void)hipStreamDestroy(c->bw.side);
   if (c->bw.ev_start) (void)hipEventDestroy(c->bw.ev_start);
   for (int i = 0; i < 2; ++i) {
@@ -827,7 +828,7 @@ extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float*
 }
 
 // critic ---------------------------------------------------------------------------------------
-static int bind_critic(gmpc_ctx* c, const float* critic, CriticDesc& cd, hipStream_t s) {
+static int bind_critic(gmpc_ctx* c, const float* critic, CriticDesc& cd, hipStream_t s, bool head_transpose = true) {
   const gmpc_shape& sh = c->sh;
   if (sh.lstm_features <= 0) return fail(GMPC_EINVAL, "this ctx was created without a critic");
   const long n = c->nx, F = sh.lstm_features;      // the critic scores x sequences
@@ -841,15 +842,35 @@ static int bind_critic(gmpc_ctx* c, const float* critic, CriticDesc& cd, hipStre
   // layers read the parameters as they lie, the head's backward layers its transposed kernels (one launch)
   if (!(c->lwp != nullptr && gmpc_lstm2_supported(cd)) || c->xT != nullptr)
     gmpc_launch_transpose((int)(n + F), (int)(4 * F), cd.Wcat, c->critT, s);
-  gmpc_launch_mlp_transpose_all(cd.head, s);
+  if (head_transpose) gmpc_launch_mlp_transpose_all(cd.head, s);     // (else: the caller, beside the LSTM forward sweep)
   return 0;
 }
 
 static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const float* label,
                                    const float* critic, int loss_kind, float* dxseq, bool want_wgrad,
                                    float* grad_sum, hipStream_t s, float* loss_sum = nullptr) {
+  // The side stream of the critic step (GMPC_CRITIC_SIDE=0: everything on the caller's stream): the transposed head
+  // kernels are built beside the LSTM forward sweep (only k_head2 reads them), the head's weight gradients and the
+  // loss sum run beside the BPTT sweep (they need k_head2's outputs only; the sweep is a latency chain at one wave
+  // per SIMD).
+  const char* side_env = getenv("GMPC_CRITIC_SIDE");
+  const bool side_on = !(side_env != nullptr && side_env[0] == '0') && c->xT == nullptr && c->lwp != nullptr;
+  if (side_on && !c->crit_side) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->crit_side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->crit_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->crit_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->crit_tr, hipEventDisableTiming));
+  }
   CriticDesc cd;
-  TRY(bind_critic(c, critic, cd, s));
+  TRY(bind_critic(c, critic, cd, s, !side_on));
+  const bool tr_side = side_on && gmpc_lstm2_supported(cd);
+  if (side_on && !tr_side) gmpc_launch_mlp_transpose_all(cd.head, s);
+  if (tr_side) {
+    HIP_TRY(hipEventRecord(c->crit_fork, s));
+    HIP_TRY(hipStreamWaitEvent(c->crit_side, c->crit_fork, 0));
+    gmpc_launch_mlp_transpose_all(cd.head, c->crit_side);
+    HIP_TRY(hipEventRecord(c->crit_tr, c->crit_side));
+  }
   const gmpc_shape& sh = c->sh;
   const int n = c->nx, F = sh.lstm_features, T1 = sh.T + 1;
   // wide inputs (n + F > 256): x_t Wx for all steps is one MFMA GEMM up front and the LSTM kernels
@@ -883,29 +904,19 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     }
     gmpc_launch_lstm_fwd(Bc, cr, xseq, c->gates, c->cs, c->hp, c->hT, widein ? c->xproj : nullptr, s);
   }
+  if (tr_side) HIP_TRY(hipStreamWaitEvent(s, c->crit_tr, 0));
   {
     ProfScope ps(c, PROF_HEAD, s);
     gmpc_launch_head2(Bc, cd, loss_kind, c->hT, label, c->cscore, c->closs, c->hacts, c->hdels, c->plast, c->dhT,
                       c->hstride, s);
   }
-  // The head's weight gradients (k_wgrad_batch + its reduction) and the loss sum need k_head2's outputs only; the
-  // BPTT sweep after it is a latency chain at one wave per SIMD.  Forked onto a side stream they run under the
-  // sweep instead of behind it (GMPC_CRITIC_SIDE=0: one stream).
   hipStream_t sw = s;
   bool forked = false;
-  if (gen2 && want_wgrad) {
-    const char* e = getenv("GMPC_CRITIC_SIDE");
-    if (!(e != nullptr && e[0] == '0')) {
-      if (!c->crit_side) {
-        HIP_TRY(hipStreamCreateWithFlags(&c->crit_side, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&c->crit_fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&c->crit_join, hipEventDisableTiming));
-      }
-      HIP_TRY(hipEventRecord(c->crit_fork, s));
-      HIP_TRY(hipStreamWaitEvent(c->crit_side, c->crit_fork, 0));
-      sw = c->crit_side;
-      forked = true;
-    }
+  if (gen2 && want_wgrad && side_on) {
+    HIP_TRY(hipEventRecord(c->crit_fork, s));
+    HIP_TRY(hipStreamWaitEvent(c->crit_side, c->crit_fork, 0));
+    sw = c->crit_side;
+    forked = true;
   }
   float* gWx0 = grad_sum;
   if (gen2 && (dxseq || want_wgrad)) {
