@@ -254,3 +254,29 @@ def test_bilevel_grad_full_shape(name, loss_kind):
                          s64["g"])
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("name", ["c3-bench", "c3-trained"])
+def test_batch_order_does_not_matter(name):
+    """Size-independent property of the whole path at BASELINE's headline size: the trajectories of a batch are
+    independent, so handing them over in another order returns the same bits in that order -- the rollout, the
+    backward pass (Jacobian chain tiles mix two samples, the sweep and its helper wave are per trajectory) and five
+    iterations of gmpc_ilqr_solve (speculative line-search rounds: the candidates of a trajectory land in other
+    work-list slots and other 16-candidate workgroups)."""
+    pb, _ = _problem(name)
+    eng = gu.engine_for(pb, critic=False)
+    d = eng.to_dev
+    perm = np.random.default_rng(5).permutation(pb["B"])
+    out = {}
+    for tag, idx in (("id", np.arange(pb["B"])), ("perm", perm)):
+        x0, U, goal = d(pb["x0"][idx]), d(pb["U"][idx]), d(pb["goal"][idx])
+        X, costs = eng.rollout_cost(x0, U, goal)
+        bw = eng.lqr_backward(X, U, goal, after_rollout=True)
+        sol = eng.ilqr_solve(x0, U, goal, {"maxiter": 5})
+        torch.cuda.synchronize()
+        out[tag] = dict(X=X.cpu().numpy(), costs=costs.cpu().numpy(), K=bw["K"].cpu().numpy(), k=bw["k"].cpu().numpy(),
+                        grad=bw["grad"].cpu().numpy(), adjoints=bw["adjoints"].cpu().numpy(),
+                        sX=sol["X"].cpu().numpy(), sU=sol["U"].cpu().numpy(), sobj=sol["obj"].cpu().numpy(),
+                        its=sol["iterations"].cpu().numpy())
+    for key, a in out["id"].items():
+        np.testing.assert_array_equal(a[perm], out["perm"][key], err_msg=key)
