@@ -280,3 +280,26 @@ def test_batch_order_does_not_matter(name):
                         its=sol["iterations"].cpu().numpy())
     for key, a in out["id"].items():
         np.testing.assert_array_equal(a[perm], out["perm"][key], err_msg=key)
+
+
+def test_the_critic_step_is_deterministic():
+    """Run-to-run determinism at the headline size: the critic step (LSTM forward, head, BPTT with the weight
+    gradients accumulated in the sweep, the head's weight gradients on the side stream, the reductions) twice on
+    the same inputs returns the same bits -- every reduction has a fixed order, nothing is accumulated with
+    floating-point atomics -- which is what keeps the parameter replicas of a multi-GPU run identical."""
+    pb, _ = _problem("c3-bench")
+    eng = gu.engine_for(pb, critic=True)
+    d = eng.to_dev
+    B = pb["B"]
+    X, _ = eng.rollout_cost(d(pb["x0"]), d(pb["U"]), d(pb["goal"]))
+    xseq = torch.cat([d(pb["true_seq"]), X])
+    label = d(np.concatenate([np.ones(B), -np.ones(B)]).astype(np.float32))
+    crit = d(gu.critic_flat(pb))
+    outs = []
+    for _ in range(3):
+        loss, grad = eng.critic_loss_grad(xseq, label, crit)
+        torch.cuda.synchronize()
+        outs.append((loss.clone(), grad.clone()))
+    for loss, grad in outs[1:]:
+        assert torch.equal(loss, outs[0][0]) and torch.equal(grad, outs[0][1])
+    assert torch.isfinite(outs[0][1]).all()
