@@ -287,18 +287,30 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   const int mb = (a.M + BM - 1) / BM, nb = (a.N + BN - 1) / BN;
-  const long total = (long)a.batch * mb * nb;
+  // upper-only outputs: the grid holds the LIVE blocks only (row block mi keeps column blocks ni >= mi BM / BN: the
+  // ones with an element on or above the diagonal), `a.upper_only` = their number per batch element.  (With the dead
+  // blocks in the grid as workgroups that return at once, a 128 x 256 tiling of T1 took the time of the full product.)
+  const int lb = a.upper_only ? a.upper_only : mb * nb;
+  const long total = (long)a.batch * lb;
   // consecutive workgroup ids go round the 8 XCDs: give every XCD one contiguous range of blocks,
   // so the blocks sharing a batch element's X / Y panels meet in the same L2
   const long per = (total + 7) / 8;
   const long item = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
   if ((long)(blockIdx.x >> 3) >= per || item >= total) return;
-  const int b = (int)(item / (mb * nb));
-  const int rem = (int)(item - (long)b * mb * nb);
-  const int mi = rem / nb, ni = rem - mi * nb;
+  const int b = (int)(item / lb);
+  int rem = (int)(item - (long)b * lb);
+  int mi, ni;
+  if (a.upper_only) {
+    mi = 0;
+    int live = nb;                                   // live blocks of row block mi
+    while (rem >= live) { rem -= live; ++mi; live = nb - (mi * BM) / BN; }
+    ni = (mi * BM) / BN + rem;
+  } else {
+    mi = rem / nb;
+    ni = rem - mi * nb;
+  }
   if (a.active != nullptr && a.active[b] == 0) return;
   const int m0 = mi * BM, n0 = ni * BN;
-  if (a.upper_only && m0 > n0 + BN - 1) return;     // no element with row <= column in this block
   // ... and in a block on the diagonal the wave whose 32 WMT x 32 WNT corner lies below it (one of four in a
   // square block) only helps with the staging: no MFMAs, no stores
   const bool dead = a.upper_only && m0 + wm * WMT * 32 > n0 + (wn * WNT + WNT) * 32 - 1;
@@ -513,9 +525,17 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_bgemm_tn_lds(BgemmArgs a) {
 #define GMPC_BG_KC 8
 #endif
 template <int WMT, int WNT>
-static void launch_lds(const BgemmArgs& a, hipStream_t s) {
+static void launch_lds(const BgemmArgs& a0, hipStream_t s) {
   constexpr int BM = 64 * WMT, BN = 64 * WNT;
-  const long total = (long)a.batch * ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  BgemmArgs a = a0;
+  const int mbk = (a.M + BM - 1) / BM, nbk = (a.N + BN - 1) / BN;
+  long lb = (long)mbk * nbk;
+  if (a.upper_only) {                 // live blocks per batch element (see the kernel)
+    lb = 0;
+    for (int mi = 0; mi < mbk; ++mi) lb += nbk - (mi * BM) / BN > 0 ? nbk - (mi * BM) / BN : 0;
+    a.upper_only = (int)lb;
+  }
+  const long total = (long)a.batch * lb;
   const long per = (total + 7) / 8;
   auto al4 = [](const void* p_, long st, int ld) {
     return p_ == nullptr || (((uintptr_t)p_ & 15) == 0 && (st & 3) == 0 && (ld & 3) == 0);
