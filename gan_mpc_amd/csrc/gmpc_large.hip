@@ -1283,8 +1283,12 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_pupdate(int n, int ng, int
                                                               const int* active, float* P) {
   constexpr int TS = GMPC_PU_TILE;
   __shared__ float tA[TS][TS + 1], dI[TS], dJ[TS];
-  const int I = blockIdx.y, J = blockIdx.x, b = blockIdx.z;
-  if (I > J) return;
+  // blockIdx.x enumerates the tile pairs I <= J only (row I holds nt - I of them): a workgroup that returns at once
+  // still waits for its dispatch slot behind the ones before it
+  const int nt_ = (n + TS - 1) / TS, b = blockIdx.z;
+  int I = 0, J = blockIdx.x;
+  while (J >= nt_ - I) { J -= nt_ - I; ++I; }
+  J += I;
   if (active != nullptr && active[b] == 0) return;
   const int tx = threadIdx.x & (TS - 1), ty = threadIdx.x / TS;      // 64 columns x 4 rows per sweep
   const size_t o = (size_t)b * n * n;
@@ -1561,7 +1565,7 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
     g.upper_only = full_t1 ? 0 : 1;
     gmpc_launch_bgemm_tn(g, s);
     if (curv) gmpc_launch_add_phi(B, n, m, w.Phi, nullptr, w.T1, s);
-    hipLaunchKernelGGL(k_big_pupdate, dim3(nt, nt, B), dim3(GMPC_THREADS), 0, s, n, w.ng > 0 ? w.ng : n, T, t, X,
+    hipLaunchKernelGGL(k_big_pupdate, dim3(nt * (nt + 1) / 2, 1, B), dim3(GMPC_THREADS), 0, s, n, w.ng > 0 ? w.ng : n, T, t, X,
                        goal, mpc_w,
                        w.sbuf, w.T1, active, w.P);
   }
