@@ -273,7 +273,7 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
 // trajectory are independent rollouts, so a round evaluates several of them speculatively
 // (k_traj<true> over a work list of (trajectory, halving count) candidates) and k_ls_decide picks,
 // per trajectory, the LARGEST accepted step of the round -- the candidate the sequential loop would
-// have stopped at -- commits it, or queues the next 4 halvings.  The first round of a trajectory
+// have stopped at -- commits it, or queues the next 4 halvings (8 from the third round on).  The first round of a trajectory
 // covers the halvings up to the one its previous line search accepted (1 candidate for a
 // well-conditioned problem that takes full steps, up to 8 for one that backtracks deeply), so the
 // rollouts stay close to the sequential loop's count while the launches drop from up to 15
@@ -343,6 +343,7 @@ __global__ __launch_bounds__(1024) void k_ls_place(int B, const int* cnt, const 
 
 struct LsDecideArgs {
   int n, m, T, Lh, k_max;
+  int next;              // candidates queued for the next round when this one accepts nothing
   float alpha_0;
   const int* slot; int* cnt; int* kfirst; int* prevk; int* run;
   const float* objc; const float* Xc; const float* Uc; const uint32_t* maskc;
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
       atomicAdd(a.stats + 16, 1);
     } else {                               // queue the next GMPC_LS_NEXT halvings (k_ls_place)
       const int left = a.k_max - (k0 + R);
-      a.cnt[b] = left < GMPC_LS_NEXT ? left : GMPC_LS_NEXT;
+      a.cnt[b] = left < a.next ? left : a.next;
       a.kfirst[b] = k0 + R;
     }
     s_acc = acc;
@@ -523,8 +524,11 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
   // halvings allowed by trajax' loop: candidate k runs while alpha_0 / 2^k > alpha_min
   int k_max = 0;
   for (float al = a.alpha_0; al > a.alpha_min && k_max < 4096; al *= 0.5f) ++k_max;
-  // worst case: a first round of one candidate, then GMPC_LS_NEXT per round
-  const int rounds = k_max > 0 ? 1 + (k_max - 1 + GMPC_LS_NEXT - 1) / GMPC_LS_NEXT : 0;
+  // worst case: a first round of one candidate, a second of GMPC_LS_NEXT, then GMPC_LS_ITEMS per round (a third round
+  // is rare -- 0.4 % of the bench solve's candidates -- and every round enqueued costs four launches whether it
+  // finds work or not: the later rounds take all they can hold, trajax' 15 step sizes are 4 rounds instead of 5)
+  int rounds = 0;
+  for (int left = k_max, r = 0; left > 0; ++r, ++rounds) left -= r == 0 ? 1 : r == 1 ? GMPC_LS_NEXT : GMPC_LS_ITEMS;
   if (rounds > GMPC_LS_ROUNDS_MAX) return -1;
   hipLaunchKernelGGL(k_ls_init, dim3((a.B + 255) / 256), dim3(256), 0, s, a.B, a.active, a.alpha_0,
                      a.alpha_min, k_max, a.iters, w.run, w.cnt, w.kfirst, w.prevk, a.alpha, a.U_step,
@@ -534,7 +538,7 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
                        w.slot, w.counts + r, w.counts + GMPC_LS_ROUNDS_MAX,
                        w.counts + GMPC_LS_ROUNDS_MAX + 1 + 24 + (r < GMPC_LS_STATS - 24 ? r : GMPC_LS_STATS - 25));
     a.item_b = w.item_b[0]; a.item_k = w.item_k[0]; a.nitems = w.counts + r; a.objc = w.objc;
-    const long max_items = (long)a.B * (r == 0 ? GMPC_LS_ITEMS : GMPC_LS_NEXT);
+    const long max_items = (long)a.B * (r == 1 ? GMPC_LS_NEXT : GMPC_LS_ITEMS);
     const int lsgrid = (int)((max_items + GMPC_TB - 1) / GMPC_TB);
     if (eval)
       eval(user, a, (int)max_items, s);
@@ -546,6 +550,7 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
       hipLaunchKernelGGL(k_traj<true>, dim3((unsigned)lsgrid), dim3(GMPC_TRAJ_THREADS), lds, s, a);
     LsDecideArgs d;
     d.n = a.n; d.m = a.m; d.T = a.T; d.Lh = a.dyn.L - 1; d.k_max = k_max;
+    d.next = r == 0 ? GMPC_LS_NEXT : GMPC_LS_ITEMS;      // size of round r + 1
     d.alpha_0 = a.alpha_0;
     d.slot = w.slot; d.cnt = w.cnt; d.kfirst = w.kfirst; d.prevk = w.prevk; d.run = w.run;
     d.objc = w.objc; d.Xc = a.Xc; d.Uc = a.Uc; d.maskc = a.maskc;
