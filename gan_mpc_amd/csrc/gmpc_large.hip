@@ -957,46 +957,59 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     }
   }
   BS_STAMP(3)
-  // lam_t = q + A^T lam ; pa = A^T p        (column c of A is read coalesced across threads; four columns of
-  // a thread and two rows at a time: 8 loads in flight instead of one)
-  for (int c0 = tid; c0 < n; c0 += 4 * blockDim.x) {
-    float vl[4] = {0.f, 0.f, 0.f, 0.f}, vp[4] = {0.f, 0.f, 0.f, 0.f};
-    int cq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) cq[q] = min(c0 + q * (int)blockDim.x, n - 1);
+  // lam_t = q + A^T lam ; pa = A^T p: column c of A is read coalesced across threads, NQ columns of a thread and RI
+  // rows at a time -- 16 loads in flight.  NQ follows n (four columns per thread at n = 376 made 2.7 loads per useful
+  // one: the clamped duplicates of columns past n); the sums run over the rows in the same order whatever RI is.
+  {
     const float* M = lowrank ? Vt : AB;
     const float* vL = lowrank ? yl : lv;
     const float* vP = lowrank ? yp : pv;
     const int rows = lowrank ? a.h : n;
-    int i = 0;
-    for (; i + 2 <= rows; i += 2) {
-      float e0[4], e1[4];
+    auto matvec = [&](auto nqc, auto ric) __attribute__((always_inline)) {
+      constexpr int NQ = decltype(nqc)::value, RI = decltype(ric)::value;
+      for (int c0 = tid; c0 < n; c0 += NQ * (int)blockDim.x) {
+        float vl[NQ], vp[NQ];
+        int cq[NQ];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { e0[q] = M[(size_t)i * nm + cq[q]]; e1[q] = M[(size_t)(i + 1) * nm + cq[q]]; }
-      const float l0 = vL[i], l1 = vL[i + 1], p0 = vP[i], p1 = vP[i + 1];
+        for (int q = 0; q < NQ; ++q) { vl[q] = 0.f; vp[q] = 0.f; cq[q] = min(c0 + q * (int)blockDim.x, n - 1); }
+        int i = 0;
+        for (; i + RI <= rows; i += RI) {
+          float e[RI][NQ], lr[RI], pr[RI];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        vl[q] = fmaf(e0[q], l0, vl[q]); vp[q] = fmaf(e0[q], p0, vp[q]);
-        vl[q] = fmaf(e1[q], l1, vl[q]); vp[q] = fmaf(e1[q], p1, vp[q]);
+          for (int r = 0; r < RI; ++r) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) e[r][q] = M[(size_t)(i + r) * nm + cq[q]];
+            lr[r] = vL[i + r];
+            pr[r] = vP[i + r];
+          }
+#pragma unroll
+          for (int r = 0; r < RI; ++r)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { vl[q] = fmaf(e[r][q], lr[r], vl[q]); vp[q] = fmaf(e[r][q], pr[r], vp[q]); }
+        }
+        for (; i < rows; ++i) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) {
+            const float ev = M[(size_t)i * nm + cq[q]];
+            vl[q] = fmaf(ev, vL[i], vl[q]); vp[q] = fmaf(ev, vP[i], vp[q]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int c = c0 + q * (int)blockDim.x;
+          if (c >= n) continue;
+          if (lowrank) { vl[q] += lv[c]; vp[q] += pv[c]; }      // A^T v = v + Vx (W_L v)
+          pa[c] = vp[q];
+          const float ln = qv[c] + vl[q];
+          a.lam[(size_t)b * n + c] = ln;
+          if (!m1) a.adj[((size_t)b * (T + 1) + t) * n + c] = ln;
+        }
       }
-    }
-    for (; i < rows; ++i) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float e = M[(size_t)i * nm + cq[q]];
-        vl[q] = fmaf(e, vL[i], vl[q]); vp[q] = fmaf(e, vP[i], vp[q]);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = c0 + q * (int)blockDim.x;
-      if (c >= n) continue;
-      if (lowrank) { vl[q] += lv[c]; vp[q] += pv[c]; }      // A^T v = v + Vx (W_L v)
-      pa[c] = vp[q];
-      const float ln = qv[c] + vl[q];
-      a.lam[(size_t)b * n + c] = ln;
-      if (!m1) a.adj[((size_t)b * (T + 1) + t) * n + c] = ln;
-    }
+    };
+    const int nq = (n + (int)blockDim.x - 1) / (int)blockDim.x;
+    if (nq <= 1) matvec(std::integral_constant<int, 1>{}, std::integral_constant<int, 16>{});
+    else if (nq == 2) matvec(std::integral_constant<int, 2>{}, std::integral_constant<int, 8>{});
+    else matvec(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
   }
   BS_STAMP(4)
   // G = sym(R + B^T P B)
