@@ -884,36 +884,42 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   const bool lowrank = a.Vt != nullptr;
   const float* Vt = lowrank ? a.Vt + (size_t)b * a.h * nm : nullptr;
   if (lowrank) {
-    // y = W_L v for v = lam, p: one wave per row of W_L (coalesced along the row), two rows and four 64-wide
-    // slices at a time so that 8 loads are in flight (one load per iteration left every one of the 16 k
+    // y = W_L v for v = lam, p: one wave per row of W_L (coalesced along the row), four rows and four 64-wide
+    // slices at a time so that 16 loads are in flight (one load per iteration left every one of the 16 k
     // loads of a wave's rows exposed: 0.68 M of the kernel's 2.8 M cycles at n = 1024, h = 200)
     const int wave = tid >> 6, ln = tid & 63;
-    for (int k = wave; k < a.h; k += 2 * (GMPC_THREADS / 64)) {
-      const int k2 = k + GMPC_THREADS / 64;
-      const bool two = k2 < a.h;
-      const float* wr0 = a.WL + (size_t)k * n;
-      const float* wr1 = a.WL + (size_t)(two ? k2 : k) * n;
-      float sl0 = 0.f, sp0 = 0.f, sl1 = 0.f, sp1 = 0.f;
+    constexpr int NW = GMPC_THREADS / 64, RW = 4;       // rows per wave and pass: 16 loads in flight
+    for (int k = wave; k < a.h; k += RW * NW) {
+      const float* wr[RW];
+      bool ok[RW];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        ok[r] = k + r * NW < a.h;
+        wr[r] = a.WL + (size_t)(ok[r] ? k + r * NW : k) * n;
+      }
+      float sl[RW], sp[RW];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) { sl[r] = 0.f; sp[r] = 0.f; }
       for (int i0 = ln; i0 < n; i0 += 256) {
-        float w0v[4], w1v[4];
+        float wv[RW][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int i = min(i0 + 64 * q, n - 1);
-          w0v[q] = wr0[i];
-          w1v[q] = wr1[i];
+#pragma unroll
+          for (int r = 0; r < RW; ++r) wv[r][q] = wr[r][i];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int i = i0 + 64 * q;
           const float lvi = i < n ? lv[i] : 0.f, pvi = i < n ? pv[i] : 0.f;
-          sl0 = fmaf(w0v[q], lvi, sl0); sp0 = fmaf(w0v[q], pvi, sp0);
-          sl1 = fmaf(w1v[q], lvi, sl1); sp1 = fmaf(w1v[q], pvi, sp1);
+#pragma unroll
+          for (int r = 0; r < RW; ++r) { sl[r] = fmaf(wv[r][q], lvi, sl[r]); sp[r] = fmaf(wv[r][q], pvi, sp[r]); }
         }
       }
-      sl0 = wave_sum(sl0); sp0 = wave_sum(sp0); sl1 = wave_sum(sl1); sp1 = wave_sum(sp1);
-      if (ln == 0) {
-        yl[k] = sl0; yp[k] = sp0;
-        if (two) { yl[k2] = sl1; yp[k2] = sp1; }
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const float a_ = wave_sum(sl[r]), b_ = wave_sum(sp[r]);
+        if (ln == 0 && ok[r]) { yl[k + r * NW] = a_; yp[k + r * NW] = b_; }
       }
     }
     __syncthreads();
@@ -926,17 +932,23 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
     const int rp = tid / MC, j = tid - rp * MC;
     float g = 0.f, h = 0.f;
     if (j < m) {
-      if (lowrank) {
-        for (int k = rp; k < a.h; k += RP) {
-          const float vkj = Vt[(size_t)k * nm + n + j];
-          g = fmaf(vkj, yl[k], g);
-          h = fmaf(vkj, yp[k], h);
-        }
-      } else
-      for (int i = rp; i < n; i += RP) {
-        const float bij = AB[(size_t)i * nm + n + j];
-        g = fmaf(bij, lv[i], g);
-        h = fmaf(bij, pv[i], h);
+      // (8 loads in flight; the sums keep the order of the one-load loop)
+      const float* Mj = (lowrank ? Vt : AB) + n + j;
+      const float* vL = lowrank ? yl : lv;
+      const float* vP = lowrank ? yp : pv;
+      const int rows = lowrank ? a.h : n;
+      int i = rp;
+      for (; i + 7 * RP < rows; i += 8 * RP) {
+        float e[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) e[r] = Mj[(size_t)(i + r * RP) * nm];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { g = fmaf(e[r], vL[i + r * RP], g); h = fmaf(e[r], vP[i + r * RP], h); }
+      }
+      for (; i < rows; i += RP) {
+        const float e = Mj[(size_t)i * nm];
+        g = fmaf(e, vL[i], g);
+        h = fmaf(e, vP[i], h);
       }
     }
     part[tid] = g;
@@ -1271,6 +1283,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_big_step(BigStepArgs a) {
   // p = q + A^T p + H^T k + K^T (G k + h)      [= q + A^T p + (H+GK)^T k + K^T h, G symmetric]
   for (int c = tid; c < n; c += blockDim.x) {
     float v1 = 0.f, v2 = 0.f;
+    // (eight rows at a time -- 16 loads in flight -- measured slower: 99 k vs 86 k cycles at the C5 shard)
     for (int i = 0; i < m; ++i) {
       v1 = fmaf(HG[(size_t)i * nm + c], kv[i], v1);
       v2 = fmaf(Kt[(size_t)i * n + c], gk[i], v2);   // own column: written by this thread above
