@@ -537,8 +537,12 @@ static void launch_lds(const BgemmArgs& a0, hipStream_t s) {
   }
   const long total = (long)a.batch * lb;
   const long per = (total + 7) / 8;
+  // 16-byte staging needs columns in groups of four (M, N multiples of 4); the ROWS need not start on 16 bytes:
+  // buffer_load_dwordx4 takes any 4-byte-aligned address (ld = n + m = 393 at C4) -- GMPC_BG_VEC_ALIGNED=1 asks for
+  // 16-byte rows as the first version did
+  static const bool want_al = [] { const char* e = getenv("GMPC_BG_VEC_ALIGNED"); return e != nullptr && e[0] == '1'; }();
   auto al4 = [](const void* p_, long st, int ld) {
-    return p_ == nullptr || (((uintptr_t)p_ & 15) == 0 && (st & 3) == 0 && (ld & 3) == 0);
+    return p_ == nullptr || !want_al || (((uintptr_t)p_ & 15) == 0 && (st & 3) == 0 && (ld & 3) == 0);
   };
   // (192-wide blocks stage 16 bytes per thread with 16-row stages only: 8 rows x 192 columns are 1.5 loads per thread)
   const bool vec = (a.M & 3) == 0 && (a.N & 3) == 0 && al4(a.X, a.sx, a.ldx) &&
