@@ -22,6 +22,9 @@
 #include <cstdlib>
 
 #include "gmpc_device.h"
+#ifndef GMPC_LIN_RD0
+#define GMPC_LIN_RD0 3      // k-steps of W_1^T fragments in flight + 1 in the wide form's input GEMM (5 or 8: C4 97 vs 91 ms)
+#endif
 
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
         for (int j = 0; j < CT; ++j)
 #pragma unroll
           for (int rg = 0; rg < 16; ++rg) acc0[j][rg] = 0.f;
-        constexpr int RD0 = 3;
+        constexpr int RD0 = GMPC_LIN_RD0;
         float aw[RD0][CT];
         auto wload = [&](int ks_, int j_) -> float {
           const unsigned r = __builtin_amdgcn_raw_buffer_load_b32(w1r, voff, (2 * ks_ * ld0 + (t0 + j_) * 32) * 4, 0);
