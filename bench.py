@@ -186,6 +186,103 @@ def cpu_baseline(args, w):
             "sample": f"median of {len(times)} steps (after 3 warm-ups) of {what}; same shapes, same step"}
 
 
+def backward_roofline(n, m, T, B, dyn_dims, ms):
+    """Roofline entry of one backward pass (`ms` per launch) of a large-state workload: the algorithmic count is
+    SURVEY 8d's dense one (Jacobian chain + the n^3 Riccati products); when the pass runs on the low-rank form of
+    the Jacobians it EXECUTES fewer flops, and `frac` is then the executed rate over the peak -- the dense-count
+    figure (which can exceed 1) stays under its own name."""
+    flops = (linearize_flops_per_sample(n, m, dyn_dims) + riccati_flops_per_sample(n, m)) * B * T
+    ach = flops / (ms * 1e-3) / 1e12
+    out = {"bound": "mfma", "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "avg_launch_ms": round(ms, 4),
+           "algorithmic_gflop_per_launch": round(flops / 1e9, 2), "executed": None}
+    if 2 * dyn_dims[-2] < n and not os.environ.get("GMPC_BIG_DENSE"):
+        ex = lowrank_flops_per_sample(n, m, dyn_dims) * B * T
+        ex_t = ex / (ms * 1e-3) / 1e12
+        out["executed"] = {"gflop_per_launch": round(ex / 1e9, 2), "TFLOPs": round(ex_t, 3),
+                           "frac_of_peak": round(ex_t / PEAK_FP32_TFLOPS, 4)}
+        out["achieved"] = round(ex_t, 3)
+        out["frac"] = round(ex_t / PEAK_FP32_TFLOPS, 4)
+        out["frac_basis"] = "flops executed by the low-rank form"
+        out["dense_count_TFLOPs"] = round(ach, 3)
+        out["dense_count_frac"] = round(ach / PEAK_FP32_TFLOPS, 4)
+    else:
+        out["achieved"] = round(ach, 3)
+        out["frac"] = round(ach / PEAK_FP32_TFLOPS, 4)
+        out["frac_basis"] = "dense algorithmic count (the pass executes it)"
+    return out
+
+
+def large_state_entry(key, steps, warmup, dev_index):
+    """A short pass of one of the large-state configurations (per-GPU shard of BASELINE.json configs 4 / 5) for the
+    `large_state` key of the headline line: the same step (rollout + costs, critic step on 2B sequences, backward
+    pass, clip+Adam), one stream, inputs resident in HBM, `steps` timed steps after `warmup`."""
+    import numpy as np
+    import torch
+    import ctypes as C
+    from gan_mpc_amd import _lib
+    from gan_mpc_amd import params as P
+    from gan_mpc_amd import synthetic
+    from gan_mpc_amd.engine import Engine
+    w = WORKLOADS[key]
+    n, m, T, F, B = w["n"], w["m"], w["T"], w["F"], w["B"]
+    mk = dict(dyn_hidden=w["dyn_hidden"], cost_hidden=w["cost_hidden"], cost_fout=w["cost_fout"],
+              lstm_features=F, head_hidden=w["head_hidden"])
+    pb = synthetic.make_problem(n, m, T, B, seed=1000, **mk)
+    wts = synthetic.make_problem(n, m, T, 1, seed=0, **mk)
+    dyn_dims = [n + m, *w["dyn_hidden"], n]
+    cost_dims = [n, *w["cost_hidden"], w["cost_fout"]]
+    head_dims = [F, *w["head_hidden"], 1]
+    eng = Engine(n, m, T, dyn_dims, cost_dims, max_batch=B, lstm_features=F, head_dims=head_dims, device=dev_index)
+    try:
+        d = eng.to_dev
+        eng.set_params(d(wts["mpc_w"]), d(P.pack_mlp(P.layers_to_tree(wts["dyn"]))),
+                       d(P.pack_mlp(P.layers_to_tree(wts["cmlp"]))))
+        critic = d(P.pack_critic(P.critic_dict_to_tree(wts["critic"])))
+        adam_m, adam_v = torch.zeros_like(critic), torch.zeros_like(critic)
+        x0, U, goal = d(pb["x0"]), d(pb["U"]), d(pb["goal"])
+        xseq = eng.new(2 * B, T + 1, n)
+        xseq[:B].copy_(d(pb["true_seq"]))
+        del pb
+        label = d(np.concatenate([np.ones(B), -np.ones(B)]).astype(np.float32))
+        X = xseq[B:]
+        costs = eng.new(B, T + 1)
+        bw = dict(K=eng.new(B, T, m, n), k=eng.new(B, T, m), grad=eng.new(B, T, m), adjoints=eng.new(B, T + 1, n),
+                  AB=None)
+        packed = torch.zeros(1 + eng.critic_count, dtype=torch.float32, device=eng.device)
+
+        def step(k):
+            eng.rollout_cost(x0, U, goal, X=X, costs=costs)
+            _lib.check(eng.lib.gmpc_critic_loss_grad(
+                eng.ctx, 2 * B, C.c_void_p(xseq.data_ptr()), C.c_void_p(label.data_ptr()),
+                C.c_void_p(critic.data_ptr()), C.c_void_p(packed[:1].data_ptr()),
+                C.c_void_p(packed[1:].data_ptr()), eng._stream()))
+            eng.lqr_backward(X, U, goal, after_rollout=True, out=bw)
+            eng.adam_clip_step(critic, packed[1:], adam_m, adam_v, k + 1, lr=1e-5, grad_scale=1.0 / (2 * B))
+
+        for k in range(warmup):
+            step(k)
+        torch.cuda.synchronize()
+        eng.profile_enable(True)
+        eng.profile_read()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(warmup + k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        ms_bw = prof["riccati"][0] / max(1, prof["riccati"][1])
+        return {"workload": w["name"], "steps": steps, "warmup": warmup, "batch_per_gpu": B,
+                "ms_per_step": round(dt / steps * 1e3, 3), "trajectories_per_sec": round(B * steps / dt, 1),
+                "kernel_ms_per_step": {kk: round(v[0] / steps, 4) for kk, v in prof.items() if v[1]},
+                "roofline": dict(kernel="large-state backward pass (Jacobian chain + batched GEMMs + k_big_step), "
+                                        "HIP events around the whole pass",
+                                 **backward_roofline(n, m, T, B, dyn_dims, ms_bw))}
+    finally:
+        eng.close()
+        torch.cuda.empty_cache()
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` from a bare shell: start N ranks with torch.distributed.run as a CHILD
     process (this parent never initialises the GPU), relay rank 0's JSON line, exit with the child's code."""
@@ -231,10 +328,18 @@ def main():
                     help="everything on one stream (default: the critic step runs on a second stream beside the "
                          "Riccati sweep, gated behind the Jacobian chain by gmpc_set_linearize_event)")
     ap.add_argument("--overlap", action="store_true", help=argparse.SUPPRESS)     # (the default since round 2)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="the optimiser step of step k is joined back into the main stream before step k + 1 starts "
+                         "(the round-3 ordering).  Default: the critic chain, its all-reduce and clip+Adam stay on the "
+                         "second stream -- step k + 1's rollout starts behind step k's Riccati sweep, the critic "
+                         "parameters are next read by step k + 1's critic chain on that same stream (two rollout "
+                         "buffers, so that step k + 1's rollout does not overwrite sequences step k's critic still reads)")
     ap.add_argument("--secondary-maxiter", type=int, default=10,
                     help="maxiter of the secondary full-bilevel measurement (0: skip)")
     ap.add_argument("--solve-maxiter", type=int, default=100,
                     help="maxiter of the complete-solve measurement inside `secondary` (0: skip)")
+    ap.add_argument("--no-large-state", action="store_true",
+                    help="skip the short C4 (5 steps) and C5 (1 step) passes attached to the headline line as `large_state`")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend: nccl (= RCCL over xGMI, the real thing) or gloo "
                          "(rehearsal of the multi-rank path on a box with fewer GPUs than ranks)")
@@ -318,26 +423,52 @@ def main():
         lin_ev.record()                      # creates the HIP event behind the handle
         eng.set_linearize_event(lin_ev)
 
-    def critic_grads():
+    # Deferred optimiser step (default with two streams): nothing on the main stream reads the critic parameters --
+    # the next reader is the NEXT step's critic chain, on the second stream -- so the critic chain, the exchange and
+    # clip+Adam of step k are never joined back: step k + 1's rollout is enqueued right behind step k's Riccati sweep
+    # and the exchange has the whole next rollout to hide behind.  The rollout of step k + 2 reuses step k's sequence
+    # buffer and waits for the event recorded behind step k's optimiser step.
+    pipe = side is not None and not args.no_pipeline
+    xbufs = [xseq]
+    if pipe:
+        xseq_b = eng.new(2 * B, T + 1, n)
+        xseq_b.copy_(xseq)
+        xbufs.append(xseq_b)
+    crit_done = [None] * len(xbufs)
+
+    def critic_grads(xs):
         _lib.check(eng.lib.gmpc_critic_loss_grad(
-            eng.ctx, 2 * B, C.c_void_p(xseq.data_ptr()), C.c_void_p(label.data_ptr()),
+            eng.ctx, 2 * B, C.c_void_p(xs.data_ptr()), C.c_void_p(label.data_ptr()),
             C.c_void_p(critic.data_ptr()), C.c_void_p(loss_view.data_ptr()),
             C.c_void_p(grad_view.data_ptr()), eng._stream()))
         return parallel.allreduce_start(packed)
 
     def step(k):
-        # rollout -> backward pass (Jacobian chain, then terminal + Riccati sweep) -> optimiser; the critic
-        # gradients and their all-reduce either before the backward pass on the same stream, or (--overlap) on a
-        # second stream that waits for the Jacobian chain and runs beside the Riccati sweep
-        eng.rollout_cost(x0, U, goal, X=X, costs=costs)
+        # rollout -> backward pass (terminal, Jacobian chain, Riccati sweep) on the main stream; the critic
+        # gradients, their all-reduce and the optimiser step on a second stream that waits for the Jacobian chain
+        # and runs beside the Riccati sweep (--no-overlap: one stream, critic before the backward pass)
+        j = k % len(xbufs)
+        xs = xbufs[j]
+        Xk = xs[B:]
+        if crit_done[j] is not None:
+            torch.cuda.current_stream().wait_event(crit_done[j])
+        eng.rollout_cost(x0, U, goal, X=Xk, costs=costs)
         if side is None:
-            work = critic_grads()
-            eng.lqr_backward(X, U, goal, after_rollout=True, out=bw)
+            work = critic_grads(xs)
+            eng.lqr_backward(Xk, U, goal, after_rollout=True, out=bw)
         else:
-            eng.lqr_backward(X, U, goal, after_rollout=True, out=bw)     # records lin_ev after the chain
+            eng.lqr_backward(Xk, U, goal, after_rollout=True, out=bw)     # records lin_ev after the chain
             side.wait_event(lin_ev)
             with torch.cuda.stream(side):
-                work = critic_grads()
+                work = critic_grads(xs)
+                if pipe:
+                    parallel.allreduce_finish(packed, work, counted=False)
+                    eng.adam_clip_step(critic, grad_view, adam_m, adam_v, k + 1, lr=1e-5, grad_scale=inv_count)
+                    if crit_done[j] is None:
+                        crit_done[j] = torch.cuda.Event()
+                    crit_done[j].record(side)
+            if pipe:
+                return
             torch.cuda.current_stream().wait_stream(side)
         parallel.allreduce_finish(packed, work, counted=False)
         eng.adam_clip_step(critic, grad_view, adam_m, adam_v, k + 1, lr=1e-5, grad_scale=inv_count)
@@ -398,21 +529,19 @@ def main():
             kname = "large-state backward (k_linearize_mfma + k_bgemm_tn_lds + k_big_step)"
             ms, cnt = prof["riccati"]
             flops = (linearize_flops_per_sample(n, m, dyn_dims) + riccati_flops_per_sample(n, m)) * B * T
-        executed = None
-        if n > 64 and 2 * dyn_dims[-2] < n and not os.environ.get("GMPC_BIG_DENSE"):
-            executed = lowrank_flops_per_sample(n, m, dyn_dims) * B * T
         ach = flops / (ms / cnt * 1e-3) / 1e12
-        roof = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3),
-                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
-                "traffic": None,
-                "avg_launch_ms": round(ms / cnt, 4),
-                "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
-                # the large-state pass on the low-rank form executes fewer flops than the dense algorithmic
-                # count `achieved` is quoted on; this is the rate of the flops actually issued
-                "executed": None if executed is None else {
-                    "gflop_per_launch": round(executed / 1e9, 2),
-                    "TFLOPs": round(executed / (ms / cnt * 1e-3) / 1e12, 3),
-                    "frac_of_peak": round(executed / (ms / cnt * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4)},
+        if n <= 64:
+            roof = {"kernel": kname, "bound": "mfma", "achieved": round(ach, 3),
+                    "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
+                    "traffic": None,
+                    "avg_launch_ms": round(ms / cnt, 4),
+                    "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
+                    "executed": None}
+        else:
+            # `frac` = the rate of the flops the pass EXECUTES over the peak (the low-rank form issues fewer than
+            # the dense algorithmic count of SURVEY 8d; that figure is kept as dense_count_frac)
+            roof = {"kernel": kname, "traffic": None, **backward_roofline(n, m, T, B, dyn_dims, ms / cnt)}
+        roof.update({
                 "dominant_by_time": dom,
                 "hbm_view": {"algorithmic_bytes_per_step": step_bytes_per_traj(n, m, T) * B,
                              "achieved_GBs_whole_step": round(
@@ -422,7 +551,7 @@ def main():
                 "streams": 1 if side is None else 2,
                 "kernel_ms_note": None if side is None else
                 "terminal / riccati (stream 1) and the critic kernels (stream 2) run side by side: their times "
-                "overlap and include the sharing; rollout and linearize run alone"}
+                "overlap and include the sharing; rollout and linearize run alone"})
         tr = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tr) and args.workload == "c3":
             try:
@@ -458,6 +587,23 @@ def main():
                              f"on {B} trajectories",
                      "trajectories_per_sec": round(B / dt2, 1), "ms": round(dt2 * 1e3, 3),
                      "iteration_histogram": {str(i): int(c) for i, c in enumerate(hist) if c}}
+        # a8-a11 on their own (the structured Hessian solve + loss adjoint + cost_vjp + batch sums), at the solution the
+        # ctx holds; kernel_ms = the Hessian-solve kernel alone (HIP events around its launch)
+        eng.profile_enable(True)
+        eng.profile_read()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            eng.bilevel_grad(B, 0, desired=desired)
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t1) / 5
+        profb = eng.profile_read()
+        eng.profile_enable(False)
+        secondary["bilevel"] = {"what": "gmpc_bilevel_grad(L2) alone: loss adjoint + structured Hessian solve + cost_vjp "
+                                        "+ weight-gradient sums",
+                                "ms": round(dtb * 1e3, 4),
+                                "kernel_ms": round(profb["riccati"][0] / max(1, profb["riccati"][1]), 4),
+                                "kernel": "Hessian solve (Riccati sweep, mode 1)"}
         if args.solve_maxiter > 0:
             kw = {"maxiter": args.solve_maxiter}
             eng.ilqr_solve(x0, U, goal, kw)             # warm-up
@@ -491,6 +637,50 @@ def main():
                              "algorithmic_mflop_per_candidate": round(roll_flops / 1e6, 3),
                              "linesearch_ms_total": round(ls_ms, 2), "linesearch_calls": ls_cnt}}
 
+    # the same solve on "trained-like" dynamics (residual head x 0.1: next_x = x + small, the state stays O(1)):
+    # trajectories stop at different iterations, so the masked iterations of the loop are timed as well
+    if secondary is not None and args.solve_maxiter > 0:
+        tdyn = [(W.copy(), b.copy()) for W, b in wts["dyn"]]
+        tdyn[-1] = ((tdyn[-1][0] * 0.1).astype(np.float32), tdyn[-1][1])
+        eng.set_params(d(wts["mpc_w"]), d(P.pack_mlp(P.layers_to_tree(tdyn))),
+                       d(P.pack_mlp(P.layers_to_tree(wts["cmlp"]))))
+        kw = {"maxiter": args.solve_maxiter}
+        eng.ilqr_solve(x0, U, goal, kw)                 # warm-up
+        eng.profile_enable(True)
+        eng.profile_read()
+        t1 = time.perf_counter()
+        sol = eng.ilqr_solve(x0, U, goal, kw)
+        dt4 = time.perf_counter() - t1
+        prof4 = eng.profile_read()
+        eng.profile_enable(False)
+        its = sol["iterations"].cpu().numpy()
+        edges = [0, 1, 2, 5, 10, 20, 50, 100, 1 << 30]
+        secondary["solve_trained"] = {
+            "what": f"gmpc_ilqr_solve(maxiter={args.solve_maxiter}) on {B} trajectories, dynamics output layer x 0.1 "
+                    "(trained-like); trajectories stop at different iterations",
+            "ms": round(dt4 * 1e3, 2), "trajectories_per_sec": round(B / dt4, 1),
+            "iterations": {"min": int(its.min()), "median": float(np.median(its)), "mean": round(float(its.mean()), 2),
+                           "max": int(its.max())},
+            "iteration_histogram_bins": {f"{lo}-{min(hi, args.solve_maxiter + 1) - 1}": int(((its >= lo) & (its < hi)).sum())
+                                         for lo, hi in zip(edges[:-1], edges[1:]) if ((its >= lo) & (its < hi)).any()},
+            "ms_total": {kk: round(v[0], 3) for kk, v in prof4.items() if v[1]},
+            "linesearch_candidates": eng.linesearch_candidates(),
+            "linesearch_stats": eng.linesearch_stats()}
+
+    # ---- the large-state configurations, briefly, so that the driver's record carries them (BASELINE.json
+    # configs 4 and 5 at their per-GPU shards): not part of `value`
+    large = None
+    if rank == 0 and world == 1 and args.workload == "c3" and not args.no_large_state:
+        eng.close()
+        del eng
+        torch.cuda.empty_cache()
+        large = {}
+        for key, st, wu in (("c4", 5, 2), ("c5", 1, 1)):
+            try:
+                large[key] = large_state_entry(key, st, wu, dev_index)
+            except Exception as exc:       # the headline line must not be lost to a failure here
+                large[key] = {"error": repr(exc)[:300]}
+
     # replicas: every rank applied the same all-reduced gradient with the same fused clip+Adam -- the parameter
     # vectors must be bitwise identical (checked on every multi-rank run, it costs one small all-gather)
     if world > 1:
@@ -522,7 +712,11 @@ def main():
                                       f"{args.backend if world > 1 else 'none'}), 1 all-reduce of critic grads/step"},
             "windows": {"n": len(win), "steps_each": args.steps, "ms_per_step_median": round(float(np.median(win)), 4),
                         "ms_per_step_min": round(min(win), 4), "ms_per_step_max": round(max(win), 4)},
-            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
+            "step_ordering": ("one stream" if side is None else
+                              "two streams, optimiser step deferred: critic chain + all-reduce + clip/Adam of step k stay "
+                              "on stream 2 beside the Riccati sweep of step k and the rollout of step k + 1"
+                              if pipe else "two streams, optimiser step joined into stream 1 at the end of every step"),
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary, "large_state": large,
         }
         print(json.dumps(out))
     if world > 1:

@@ -22,7 +22,7 @@ void gmpc_launch_masks(int, int, int, int, const MlpDesc&, const float*, const f
 int gmpc_launch_linearize(int, int, int, int, const MlpDesc&, const uint32_t*, const int*, float*,
                           hipStream_t);
 int gmpc_launch_linearize_regs(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
-                               const int*, float*, int, int, hipStream_t);
+                               const int*, float*, int, int, hipStream_t, hipEvent_t mid_event = nullptr);
 int gmpc_launch_linearize_mfma(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
                                const int*, float*, int, int, hipStream_t);
 const char* gmpc_linearize_regs_last_name();
@@ -652,6 +652,7 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     return 0;
   };
   if (terminal_first) TRY(run_terminal());
+  bool lin_event_done = false;
   {
     ProfScope ps(c, PROF_LINEARIZE, s);
     // matrix-core chain; the VALU chain only serves shapes the MFMA tiling does not cover (or
@@ -662,12 +663,15 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     }();
     // 1st choice: register-resident chain (compiled for the common equal-width shapes), 2nd: the
     // LDS-operand chain (any shape), 3rd: VALU
+    int rc_regs = -1;
     if (c->dynl) {
       gmpc_launch_dynl_jac(B, sh.T, sh.T, 0, c->dl, X, U, active, AB, s);
       c->lin_kernel = "k_dynl_jac";
-    } else if (force == 0 && gmpc_launch_linearize_regs(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active,
-                                                 AB, 1, 0, s) == 0) {
+    } else if (force == 0 && (rc_regs = gmpc_launch_linearize_regs(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks,
+                                                                   active, AB, 1, 0, s, c->lin_event)) >= 0) {
+      // (rc 1: the caller's event sits between the chain's full rounds and its ragged last round)
       c->lin_kernel = gmpc_linearize_regs_last_name();
+      lin_event_done = rc_regs == 1;
     } else if (force == 2 ||
         gmpc_launch_linearize_mfma(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active, AB, 1, 0,
                                    s) != 0) {
@@ -679,7 +683,7 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     }
   }
   HIP_TRY(hipGetLastError());
-  if (c->lin_event) HIP_TRY(hipEventRecord(c->lin_event, s));     // gmpc_set_linearize_event
+  if (c->lin_event && !lin_event_done) HIP_TRY(hipEventRecord(c->lin_event, s));     // gmpc_set_linearize_event
   if (!terminal_first) TRY(run_terminal());
   HIP_TRY(hipGetLastError());
   RiccatiArgs r;
@@ -1402,7 +1406,10 @@ extern "C" int gmpc_bilevel_grad(gmpc_ctx* c, int B, int loss_kind, const float*
       gmpc_launch_dynl_curv(B, T, T, 0, c->dl, c->Xs, c->Us, c->adjs, nullptr, c->phi, s);
       r.Phi = c->phi;
     }
-    gmpc_launch_riccati(r, s);
+    {
+      ProfScope ps(c, PROF_RICCATI, s);      // (bench.py: secondary.bilevel.kernel_ms)
+      gmpc_launch_riccati(r, s);
+    }
   }
   gmpc_launch_costvjp(B, T, n, m, c->cost, c->mpc_w, sign, c->Xs, c->Us, c->goals, c->nx, c->Hout, c->dX,
                       c->gmpc, c->cact, c->cdel, c->cstride, s);

@@ -249,6 +249,11 @@ __global__ __launch_bounds__(GMPC_THREADS, NG == 1 ? 2 : 1) void k_lstm_bwd2(
       transpose_rows4(z);                       // lane (gate q, ul): z[s] = dz[column][slot s]
       if (WANT_W) db += (z[0] + z[1]) + (z[2] + z[3]);
       zbuf[gi][w][l] = make_float4(z[0], z[1], z[2], z[3]);
+      // cross-lane exchange inside ONE wave (its LDS accesses execute in order): wavefront-scope fences keep the
+      // compiler from forwarding or reordering across it, no instruction is emitted
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       float az[4];
       const float* zf = reinterpret_cast<const float*>(&zbuf[gi][w][0]);
 #pragma unroll

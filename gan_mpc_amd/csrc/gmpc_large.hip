@@ -1409,7 +1409,7 @@ __global__ void k_big_cont(int B, int T, int m, const float* U, const float* gn2
 // ------------------------------------------------------------------------------------------------
 int gmpc_launch_linearize_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
                                const uint32_t* masks, const int* active, float* AB, int samp_mul,
-                               int samp_add, hipStream_t s);
+                               int samp_add, hipStream_t s, hipEvent_t mid_event = nullptr);
 int gmpc_launch_linearize_mfma(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
                                const uint32_t* masks, const int* active, float* AB, int samp_mul,
                                int samp_add, hipStream_t s);

@@ -60,10 +60,12 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // [A | B] four at a time with its weight operands through buffer loads, and the accumulator tiles -- lanes are
 // stacked rows here -- are transposed through a wave-private LDS tile so that the rows of AB are written in
 // 128-byte segments.
-template <int NT, int KS, int TAIL = 0, bool WIDE = false>
+// REST: the same kernel under a second name -- the launch that runs the ragged last round on its own (launch_regs), so
+// that a kernel trace lists it on a row of its own
+template <int NT, int KS, int TAIL = 0, bool WIDE = false, bool REST = false>
 __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linearize_regs(
     int NSamp, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
-    float* AB, int ntiles, int samp_mul, int samp_add) {
+    float* AB, int ntiles, int samp_mul, int samp_add, int tile0) {
   static_assert(NT <= 8 && 2 * KS <= 32 * NT + TAIL && (TAIL == 0 || TAIL == 8), "shape");
   constexpr bool AG = GMPC_REGS_OCC(NT, TAIL) == 1;      // register half of the accumulators (mfma_fence)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -100,7 +102,9 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
   // (static split: 27,200 tiles over 2,048 waves are 13.28 per wave, 14 rounds.  Handing the tiles out through a
   // global ticket counter -- requested before the input GEMM, read after the stores, so its round trip is off the
   // critical path -- was measured in round 3 and is not kept: 1.121 vs 1.107 ms on the same box.)
-  for (int tile = blockIdx.x * (GMPC_THREADS / 64) + wave; tile < ntiles;
+  // (tile0: first tile of this launch -- the ragged last round of a long tile list can be a launch of its own, so
+  // that a caller's event between the two lets other streams use the wave slots the last round leaves idle)
+  for (int tile = tile0 + blockIdx.x * (GMPC_THREADS / 64) + wave; tile < ntiles;
        tile += gridDim.x * (GMPC_THREADS / 64)) {
     const int r0 = tile * 32;
     int R = r0 + l31;                          // this lane's stacked Jacobian row
@@ -349,10 +353,15 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
 static char g_last_name[64] = "";
 const char* gmpc_linearize_regs_last_name() { return g_last_name; }
 
+// mid_event (optional): when the static split leaves a ragged last round -- less than GMPC_LIN_SPLIT_MAX of the wave
+// slots busy for a whole tile time (C3: 27,200 tiles over 2,048 slots = 13 full rounds + 576 tiles, 28 %) -- the last
+// round is launched as a kernel of its own and the event is recorded between the two: a stream waiting for it (the
+// critic chain, bench.py) starts while the last tiles are still running, on the CUs and register halves they leave
+// free.  Returns 1 when the event was recorded here, 0 when it was not (one launch), -1 on an unsupported shape.
 template <int NT, int KS, int TAIL = 0, bool WIDE = false>
 static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
                        const uint32_t* masks, const int* active, float* AB, int samp_mul, int samp_add,
-                       hipStream_t s) {
+                       hipStream_t s, hipEvent_t mid_event = nullptr) {
   const long Rtot = (long)NSamp * n;
   if (Rtot >= (1L << 31) - 64) return -1;
   const int ntiles = (int)((Rtot + 31) / 32);
@@ -368,16 +377,31 @@ static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const
   // (measured, round 3: one workgroup per CU -- 256 of the 512 registers of every SIMD left to other kernels --
   // costs 5.5 % alone (1.141 -> 1.204 ms), and the critic's kernels beside it are starved by its back-to-back
   // 64-cycle MFMAs: k_head2 0.05 -> 0.37 ms, k_lstm_bwd2 0.11 -> 0.87 ms.  The chain keeps the chip to itself.)
-  hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, WIDE>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
-                     dyn, lp, masks, active, AB, ntiles, samp_mul, samp_add);
   snprintf(g_last_name, sizeof(g_last_name), "k_linearize_regs<%d, %d, %d, %s>", NT, KS, TAIL, WIDE ? "true" : "false");
+  const int slots = grid * 4;
+  const int full = ntiles / slots, rest = ntiles - full * slots;
+  static const int split_pct = []() {
+    const char* e = getenv("GMPC_LIN_SPLIT");      // percent of a round below which the last round is split off; 0: never
+    return e != nullptr ? atoi(e) : 60;
+  }();
+  if (mid_event != nullptr && active == nullptr && full >= 2 && rest > 0 && rest * 100 < slots * split_pct) {
+    hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, WIDE>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
+                       dyn, lp, masks, active, AB, full * slots, samp_mul, samp_add, 0);
+    if (hipEventRecord(mid_event, s) != hipSuccess) return -1;
+    hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, WIDE, !WIDE>), dim3((rest + 3) / 4), dim3(GMPC_THREADS), lds, s,
+                       NSamp, T, n, m, dyn, lp, masks, active, AB, ntiles, samp_mul, samp_add, full * slots);
+    return 1;
+  }
+  hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, WIDE>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
+                     dyn, lp, masks, active, AB, ntiles, samp_mul, samp_add, 0);
   return 0;
 }
 
-// returns 0 on launch, -1 when the shape is not one this variant is compiled for
+// returns 0 on launch (1: and mid_event was recorded between its two launches), -1 when the shape is not one this
+// variant is compiled for
 int gmpc_launch_linearize_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
                                const uint32_t* masks, const int* active, float* AB, int samp_mul,
-                               int samp_add, hipStream_t s) {
+                               int samp_add, hipStream_t s, hipEvent_t mid_event) {
   const int Lh = dyn.L - 1;
   if (Lh < 2) return -1;
   const int H = dyn.dims[1];
@@ -387,18 +411,18 @@ int gmpc_launch_linearize_regs(int NSamp, int T, int n, int m, const MlpDesc& dy
     // wide inputs (large-state path): the 200-wide instantiation only
     static const bool off = getenv("GMPC_LIN_WIDE") != nullptr && getenv("GMPC_LIN_WIDE")[0] == '0';
     if (off || H != 200 || lp.NT != 7 || 32 * lp.NTF * lp.NGF < ((n + m + 31) / 32 + 3) / 4 * 4 * 32) return -1;
-    return launch_regs<6, 100, 8, true>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
+    return launch_regs<6, 100, 8, true>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s) < 0 ? -1 : 0;
   }
   if (lp.NTF != 1 || lp.NGF != 1) return -1;
   if (H == 200 && lp.NT == 7) {
     static const bool no_tail = getenv("GMPC_LIN_NOTAIL") != nullptr;
     if (!no_tail)
-      return launch_regs<6, 100, 8>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
-    return launch_regs<7, 100>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
+      return launch_regs<6, 100, 8>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s, mid_event);
+    return launch_regs<7, 100>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s, mid_event);
   }
   if (H == 128 && lp.NT == 4)
-    return launch_regs<4, 64>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
+    return launch_regs<4, 64>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s, mid_event);
   if (H == 64 && lp.NT == 2)
-    return launch_regs<2, 32>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s);
+    return launch_regs<2, 32>(NSamp, T, n, m, dyn, lp, masks, active, AB, samp_mul, samp_add, s, mid_event);
   return -1;
 }

@@ -25,7 +25,15 @@ typedef float f32x16_w __attribute__((ext_vector_type(16)));
 #ifdef GMPC_RICCATI_W_BARRIERS
 #define RW_SYNC() __syncthreads()
 #else
-#define RW_SYNC() __builtin_amdgcn_wave_barrier()
+// wave_barrier alone is a scheduling barrier the optimiser models as touching no memory: the wavefront-scope fences
+// around it are what tells the compiler that LDS stores before it are visible to the loads after it (they emit no
+// instruction at this scope -- in particular no s_waitcnt vmcnt --, the hardware keeps one wave's LDS accesses in order)
+#define RW_SYNC()                                             \
+  do {                                                        \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+    __builtin_amdgcn_wave_barrier();                          \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+  } while (0)
 #endif
 
 template <int N_, int M_>
