@@ -45,6 +45,8 @@ void gmpc_linpad_prepare(const MlpDesc&, int, int, float*, size_t, LinPad*, hipS
 int gmpc_launch_terminal(int, int, int, const MlpDesc&, const float*, const float*, const int*,
                          float*, float*, hipStream_t);
 void gmpc_launch_riccati(const RiccatiArgs&, hipStream_t);
+bool gmpc_riccati_w2h_shape(const RiccatiArgs&);
+void gmpc_launch_riccati_w2h(const RiccatiArgs&, const float* lx, float* bvec_out, hipStream_t);
 size_t gmpc_riccati_lds_bytes(int n, int m);
 void gmpc_launch_transpose(int, int, const float*, float*, hipStream_t);
 void gmpc_launch_lstm_fwd(int, const CriticDesc&, const float*, float*, float*, float*, float*,
@@ -1394,19 +1396,23 @@ extern "C" int gmpc_bilevel_grad(gmpc_ctx* c, int B, int loss_kind, const float*
                                  c->dynl ? &c->dl : nullptr, c->Xs, c->Us) != 0)
       return fail(GMPC_EINVAL, "large-state bilevel: Jacobian kernel does not cover this shape");
   } else {
-    gmpc_launch_bvec(B, T, n, m, c->AB, c->lx, c->Bvec, s);
     RiccatiArgs r;
     memset(&r, 0, sizeof(r));
     r.B = B; r.n = n; r.ng = c->nx; r.m = m; r.T = T; r.mode = 1;
     r.X = c->Xs; r.U = c->Us; r.goal = c->goals; r.mpc_w = c->mpc_w; r.AB = c->AB; r.QT = c->QT;
     r.qT = c->qT; r.K = c->Ks; r.k = c->ks; r.Bvec = c->Bvec; r.Hout = c->Hout; r.dX = c->dX;
-    if (c->dynl) {
-      // smooth dynamics: the dense Hessian the reference solves with carries lam_{t+1} . d^2 f (oracle
-      // second_order_lqr); lam = the adjoints of the solve's last backward pass
-      gmpc_launch_dynl_curv(B, T, T, 0, c->dl, c->Xs, c->Us, c->adjs, nullptr, c->phi, s);
-      r.Phi = c->phi;
-    }
-    {
+    if (!c->dynl && gmpc_riccati_w2h_shape(r)) {
+      // two waves per trajectory, products on the matrix pipe, the loss adjoint (a8) in the same sweep
+      ProfScope ps(c, PROF_RICCATI, s);      // (bench.py: secondary.bilevel.kernel_ms)
+      gmpc_launch_riccati_w2h(r, c->lx, c->Bvec, s);
+    } else {
+      gmpc_launch_bvec(B, T, n, m, c->AB, c->lx, c->Bvec, s);
+      if (c->dynl) {
+        // smooth dynamics: the dense Hessian the reference solves with carries lam_{t+1} . d^2 f (oracle
+        // second_order_lqr); lam = the adjoints of the solve's last backward pass
+        gmpc_launch_dynl_curv(B, T, T, 0, c->dl, c->Xs, c->Us, c->adjs, nullptr, c->phi, s);
+        r.Phi = c->phi;
+      }
       ProfScope ps(c, PROF_RICCATI, s);      // (bench.py: secondary.bilevel.kernel_ms)
       gmpc_launch_riccati(r, s);
     }

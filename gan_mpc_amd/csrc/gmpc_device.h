@@ -195,6 +195,8 @@ struct TrajArgs {
   // work lists of at least ls_split items are k_ls16's, shorter ones k_traj_rw's (0: no split, see
   // gmpc_ls16.hip); both kernels are launched and read the round's count
   int ls_split;
+  // ... and lists of at least ls32_split items k_ls32's (two groups of 16 per workgroup, gmpc_ls32.hip; 0: never)
+  int ls32_split;
 };
 
 #define GMPC_LS_ITEMS 8   // candidates per trajectory held at once by the line search

@@ -382,7 +382,10 @@ static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const
   const int full = ntiles / slots, rest = ntiles - full * slots;
   static const int split_pct = []() {
     const char* e = getenv("GMPC_LIN_SPLIT");      // percent of a round below which the last round is split off; 0: never
-    return e != nullptr ? atoi(e) : 60;
+    // (default 0 -- measured in round 4 and not kept: with the critic chain gated on the event between the two
+    // launches the chain runs 0.04 ms longer (the last round's workgroups restage their LDS tables and share their
+    // SIMDs with the critic's first kernel) and the step is 0.006 ms slower, not faster)
+    return e != nullptr ? atoi(e) : 0;
   }();
   if (mid_event != nullptr && active == nullptr && full >= 2 && rest > 0 && rest * 100 < slots * split_pct) {
     hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, WIDE>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,

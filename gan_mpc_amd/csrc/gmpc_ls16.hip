@@ -116,6 +116,7 @@ __global__ __launch_bounds__(LS16_THREADS, 1) void k_ls16(TrajArgs a) {
 #endif
   const int cnt = *a.nitems;
   if (cnt < a.ls_split) return;                 // short work list: k_traj_rw's round
+  if (a.ls32_split > 0 && cnt >= a.ls32_split) return;      // more than one pass over the chip: k_ls32's round
   const int b0 = blockIdx.x * LS16_C;
   if (b0 >= cnt) return;
   if (tid < LS16_C) {

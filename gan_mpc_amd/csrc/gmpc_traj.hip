@@ -380,6 +380,7 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
       a.run[b] = 0;
       a.cnt[b] = 0;
       atomicAdd(a.stats + min(k0 + acc, 15), 1);
+      atomicMax(a.stats + 17, k0 + acc);       // deepest halving accepted since the solve began
     } else if (k0 + R >= a.k_max) {      // every step size down to alpha_min failed
       a.alpha[b] = halved(a.k_max);
       a.U_step[b] = 0.f;
@@ -389,6 +390,9 @@ __global__ __launch_bounds__(GMPC_THREADS) void k_ls_decide(LsDecideArgs a) {
       a.cnt[b] = 0;
       atomicAdd(a.stats + 16, 1);
     } else {                               // queue the next GMPC_LS_NEXT halvings (k_ls_place)
+      // (round 4, measured and not kept: a second round that reaches the deepest halving any trajectory of the batch
+      // has accepted so far -- the third round it was meant to remove only exists in a solve's first iteration, and
+      // the longer second round cost 0.2 ms per iteration)
       const int left = a.k_max - (k0 + R);
       a.cnt[b] = left < a.next ? left : a.next;
       a.kfirst[b] = k0 + R;
@@ -493,6 +497,9 @@ void gmpc_launch_traj_rw(const TrajArgs& a, bool ls, int grid, size_t lds, hipSt
 bool gmpc_ls16_shape(const TrajArgs& a);
 int gmpc_ls16_split();
 void gmpc_launch_ls16(const TrajArgs& a, long max_items, hipStream_t s);
+bool gmpc_ls32_shape(const TrajArgs& a);
+int gmpc_ls32_split();
+void gmpc_launch_ls32(const TrajArgs& a, long max_items, int min_items, hipStream_t s);
 
 void gmpc_launch_rollout(const TrajArgs& a0, hipStream_t s) {
   TrajArgs a = a0;
@@ -518,6 +525,8 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
   if (rw) a.aw = traj_aw(a.n, a.m, a.dyn, &a.cost);
   const bool ls16 = rw && gmpc_ls16_shape(a);
   a.ls_split = ls16 ? gmpc_ls16_split() : 0;
+  const bool ls32 = ls16 && gmpc_ls32_shape(a) && (long)a.B * GMPC_LS_ITEMS >= gmpc_ls32_split();
+  a.ls32_split = ls32 ? gmpc_ls32_split() : 0;
   const size_t lds = eval ? 0 : rw ? gmpc_traj_rw_lds(a) : traj_lds(a);
   static bool attr = false;
   if (!attr && !eval) { traj_attr(&k_traj<true>); attr = true; }
@@ -544,8 +553,11 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
       eval(user, a, (int)max_items, s);
     else if (rw) {
       // short lists: 4 candidates per workgroup; long lists: 16 (each kernel returns on the other's rounds)
+      // (three forms, each launch returns at once when the round's count is another form's: 4 candidates per
+      // workgroup for short lists, 16 up to one pass over the chip, two groups of 16 beyond)
       gmpc_launch_traj_rw(a, true, lsgrid, lds, s);
       if (ls16) gmpc_launch_ls16(a, max_items, s);
+      if (ls32) gmpc_launch_ls32(a, max_items, a.ls32_split, s);
     } else
       hipLaunchKernelGGL(k_traj<true>, dim3((unsigned)lsgrid), dim3(GMPC_TRAJ_THREADS), lds, s, a);
     LsDecideArgs d;

@@ -287,7 +287,7 @@ class Engine:
         rounds = v[24:64]
         while rounds and rounds[-1] == 0:
             rounds.pop()
-        return {"accepted": v[:16], "exhausted": v[16], "round_items": rounds}
+        return {"accepted": v[:16], "exhausted": v[16], "deepest_accepted": v[17], "round_items": rounds}
 
     PROF_SLOTS = ("rollout", "linearize", "terminal", "riccati", "linesearch", "lstm_fwd", "head",
                   "lstm_bwd", "wgrad", "adam")

@@ -17,6 +17,68 @@ def fmt(v):
     return "—" if v is None else f"{v:.2e}"
 
 
+# why a stage states a tolerance above the north star's 1e-5 (first match wins; keyed on test / stage text)
+REASONS = [
+    ("share of trajectories", "not an error figure: the share of trajectories whose control flow is decided (fp32 / fp64 / "
+                              "perturbed fp32 oracles agree, no criterion within 2 % of its threshold); `tol` = the share required"),
+    ("Hessian solve residual", "backward error of the structured Hessian solve against the fp64 operator: the m x m pivoted "
+                                 "solves inherit cond(R) ~ 1e4 (alpha = 1e-2 in the stage cost); bar 1e-4 or 10 x the fp32 oracle's"),
+    ("Hessian-solve residual", "as above, at the full shapes"),
+    ("gradient response", "information only: what a right-hand-side perturbation of the size of HIP's residual does to the "
+                          "gradient in fp64 (sets the end-to-end bar)"),
+    ("round-2 fixed bar", "the round-2 fixed bar of the end-to-end gradient, kept as a recorded check (information)"),
+    ("bilevel grad end-to-end", "forward error of the gradient = the Hessian solve's backward error seen through cond(A): bar "
+                                "= max(1e-4, 4 x the fp64 response to a residual of HIP's size), never above 1e-3; the round-2 "
+                                "fixed 1e-4 bar is recorded beside it"),
+    ("bilevel Bvec", "loss adjoint at the full shapes through T = 50 .. 100 Jacobian products; achieved 1e-5 .. 1e-4"),
+    ("tangent roll", "dX rolled forward from the GPU's own H through T Jacobians (fp64 roll of the same H as reference)"),
+    ("cost_vjp", "sum over the batch of per-trajectory vector-Jacobian products taken at the GPU's own (H, dX)"),
+    ("(<= 1 iteration)", "one iLQR step: the iterate carries the Riccati gains' conditioning-limited error (cond(R) ~ 1e4: the "
+                         "NumPy fp32 oracle shows the same size), GAIN_CEILING applies"),
+    ("ilqr ", "one iLQR iteration at the full shapes: gains' conditioning (see gain rows), bar 1e-4 + the 4 x fp32-oracle rule"),
+    ("ls16 ", "iterate after 1 - 2 iLQR iterations through the 16-candidate line search: gains' conditioning"),
+    (" obj", "objective after several chaotic, ill-conditioned Newton steps (1 .. 12 iterations); bar 1e-5 .. 3e-4 by scenario"),
+    ("test_ilqr_single_iteration_teacher_forced", "one iLQR iteration from identical starts: gains' conditioning"),
+    ("test_loss_and_grad", "batch-mean bilevel gradient through the host mirror: the Hessian solve's conditioning"),
+    ("lstm-dynamics", "LSTM dynamics variant, whole policy step: gains' and Hessian solve's conditioning through the smooth cell"),
+]
+
+
+def reason(r):
+    key = r.get("test", "") + " " + r["stage"]
+    for pat, why in REASONS:
+        if pat in key:
+            return why
+    return "chained fp32 stage downstream of the Riccati gains / Hessian solve (conditioning-limited)"
+
+
+def loose_table(recs):
+    loose = [r for r in recs if r["tol"] > 1.0001e-5 and "share of trajectories" not in r["stage"]]
+    print("## Assertions whose STATED tolerance is above 1e-5\n")
+    print(f"{len(loose)} of {len(recs)} assertions state a tolerance above the north star's 1e-5; grouped by test and stage "
+          "(`n`: assertions in the group, over shapes / parameters; errors: the group's maxima).\n")
+    print("| test | stage | n | stated tol | max e_hip | max e_o32 | why the stage cannot be asked for 1e-5 |")
+    print("|---|---|---:|---:|---:|---:|---|")
+    groups = OrderedDict()
+    for r in loose:
+        t = r.get("test", "").split("::")[-1].split("[")[0]
+        groups.setdefault((t, r["stage"]), []).append(r)
+    for (t, stage), rows in groups.items():
+        tols = sorted({float(f"{x['tol']:.1e}") for x in rows})
+        tol_s = fmt(tols[0]) if len(tols) == 1 else f"{fmt(tols[0])} .. {fmt(tols[-1])}"
+        print(f"| {t} | {stage} | {len(rows)} | {tol_s} | {fmt(max(x['e_hip'] for x in rows))} | "
+              f"{fmt(max((x.get('e_o32') or 0.0) for x in rows))} | {reason(rows[0])} |")
+    print()
+    shares = [r for r in recs if "share of trajectories" in r["stage"]]
+    if shares:
+        print("## Control-flow tests: share of trajectories compared\n")
+        print("| scenario | observed share | required |")
+        print("|---|---:|---:|")
+        for r in shares:
+            print(f"| {r['stage'].split(':')[0]} ({r.get('config', '')}) | {r['e_hip']:.2f} | {r['tol']:.2f} |")
+        print()
+
+
 def main():
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "parity_records.jsonl")
     recs = [json.loads(line) for line in open(path) if line.strip()]
@@ -35,6 +97,7 @@ def main():
           "error with the denominator floored at 1e-6 x max|ref| (p99.9 beside it).\n")
     print(f"{len(recs)} assertions, {on_tol} on the tolerance branch, {len(recs) - on_tol} on the slack branch, "
           f"{sum(1 for r in recs if not r.get('passed', True))} failed.\n")
+    loose_table(recs)
     by_cfg = OrderedDict()
     for r in recs:
         by_cfg.setdefault(r.get("config", ""), []).append(r)

@@ -97,7 +97,11 @@ def _alphas(trace, B):
     return [[tr["alpha"][b] for i, tr in enumerate(trace[1:], 1) if trace[i - 1]["active"][b]] for b in range(B)]
 
 
-def _run(pb, kw, U=None, min_agree=0.6, label="", tol=1e-4):
+def _run(pb, kw, U=None, min_agree=0.6, label="", tol=1e-4, tol_obj=None):
+    """tol: bar of the one-step iterates (U, X); tol_obj: bar of the objective (default: tol).  min_agree: the share of
+    trajectories whose control flow has to be DECIDED (see the module docstring) -- set per scenario to what the
+    scenario shows (the observed share is recorded in the parity log next to the assertions)."""
+    tol_obj = tol if tol_obj is None else tol_obj
     U = pb["U"] if U is None else U
     B = U.shape[0]
     gu.set_config(f"control-flow {label} n={pb['n']} m={pb['m']} T={pb['T']} B={B}")
@@ -113,6 +117,9 @@ def _run(pb, kw, U=None, min_agree=0.6, label="", tol=1e-4):
             ap = _alphas(tp, B)
             agree &= np.array([rp[6][b] == r64[6][b] and _f32(ap[b]) == _f32(a64[b]) for b in range(B)])
         agree &= ~_near_threshold(t64, kw, B)
+        gu._record(dict(stage=f"{label}: share of trajectories whose control flow is decided (required {min_agree})",
+                        config=gu.CURRENT_CONFIG[0], e_hip=float(agree.mean()), e_o32=None, tol=min_agree,
+                        tol_used=min_agree, branch="info", entries=int(B), passed=bool(agree.mean() >= min_agree)))
         assert agree.mean() >= min_agree, f"the control flow of {agree.sum()} of {B} trajectories only is decided"
         out = eng.ilqr_solve(d(pb["x0"]), d(U), d(pb["goal"]), kw)
         it = out["iterations"].cpu().numpy()
@@ -140,7 +147,7 @@ def _run(pb, kw, U=None, min_agree=0.6, label="", tol=1e-4):
                 gu.assert_parity(f"{label} {key} (<= 1 iteration)", out[key].cpu().numpy()[one], r32[j][one],
                                  r64[j][one], tol=tol, ceiling=gu.GAIN_CEILING, el_tol=1.0)
         if fin.any():
-            gu.assert_parity(f"{label} obj", out["obj"].cpu().numpy()[fin], r32[2][fin], r64[2][fin], tol=tol,
+            gu.assert_parity(f"{label} obj", out["obj"].cpu().numpy()[fin], r32[2][fin], r64[2][fin], tol=tol_obj,
                              ceiling=gu.GAIN_CEILING)
         nanb = np.isnan(r64[2])
         assert np.isnan(out["obj"].cpu().numpy()[nanb]).all()
@@ -155,14 +162,14 @@ def test_full_steps_on_a_tame_problem():
     pb["U"] = (pb["U"] * 1e-2).astype(np.float32)
     # (|u| ~ a = 1e-2 and two iterations: with |u| << a the tame problem is converged to fp32 rounding after one
     # step and its next line search compares noise -- the CPU test runs that form in fp64, for five iterations)
-    eng, out, r64, agree = _run(pb, {"maxiter": 2}, label="full steps")
+    eng, out, r64, agree = _run(pb, {"maxiter": 2}, label="full steps", tol=1e-5, min_agree=1.0)
     assert (out["iterations"].cpu().numpy() == 2).all()
     eng.close()
 
 
 def test_deep_backtracking():
     pb = _problem(3, out_scale=1.0, B=4)
-    eng, out, r64, agree = _run(pb, {"maxiter": 6}, label="deep backtracking", tol=1e-3)
+    eng, out, r64, agree = _run(pb, {"maxiter": 6}, label="deep backtracking", tol=1e-4, tol_obj=3e-5, min_agree=0.75)
     eng.close()
 
 
@@ -170,7 +177,7 @@ def test_nan_start_never_iterates_and_neighbours_do():
     pb = _problem(5, out_scale=0.05)
     U = pb["U"].copy()
     U[1, 2, 0] = np.nan
-    eng, out, r64, agree = _run(pb, {"maxiter": 4}, U, label="nan start")
+    eng, out, r64, agree = _run(pb, {"maxiter": 4}, U, label="nan start", min_agree=1.0)
     it = out["iterations"].cpu().numpy()
     assert it[1] == 0 and it[0] > 0 and it[2] > 0
     assert np.isnan(out["obj"].cpu().numpy()[1])
@@ -190,7 +197,8 @@ def test_nan_start_never_iterates_and_neighbours_do():
 def test_each_threshold_of_the_continuation_criterion(kw):
     pb = _problem(7, out_scale=0.6, B=4)
     kw = dict(kw, maxiter=12)
-    eng, out, r64, agree = _run(pb, kw, label="threshold " + "/".join(kw), tol=1e-3)
+    # (round 4: 1e-4 where round 3 allowed 1e-3 -- the achieved errors are 1e-8 .. 1e-4, profiles/parity_r04.md)
+    eng, out, r64, agree = _run(pb, kw, label="threshold " + "/".join(kw), tol=1e-4, min_agree=0.75)
     with np.errstate(all="ignore"):
         q = orc.cast_problem(pb, np.float64)
         base = orc.ilqr(q["dyn"], q["cmlp"], q["mpc_w"], q["goal"], q["x0"], q["U"], {"maxiter": 12})
@@ -211,7 +219,7 @@ def _noop_check(eng, pb, kw, stop):
 def test_members_stop_at_different_iterations_and_the_enqueued_tail_is_a_no_op():
     pb = _problem(9, out_scale=0.6, B=5)
     kw = {"maxiter": 15, "obj_step_threshold": 0.01}
-    eng, out, r64, agree = _run(pb, kw, label="heterogeneous stops", tol=1e-3)
+    eng, out, r64, agree = _run(pb, kw, label="heterogeneous stops", tol=1e-4, tol_obj=1e-5, min_agree=0.8)
     it = out["iterations"].cpu().numpy()
     assert len(set(it.tolist())) > 1 and it.max() < 15
     # every trajectory has stopped on the threshold before maxiter: later iterations must change nothing
@@ -219,16 +227,20 @@ def test_members_stop_at_different_iterations_and_the_enqueued_tail_is_a_no_op()
     eng.close()
 
 
-@pytest.mark.parametrize("ls16", [False, True])
+@pytest.mark.parametrize("ls16", [False, True, "ls32"])
 def test_headline_shape_heterogeneous_stops(ls16, monkeypatch):
-    """n = 17, m = 6, hidden 3 x 200 (the register-weight rollout / one-wave Riccati / MFMA chain kernels; ls16: the
-    16-candidate line search forced for every round), 40 trajectories that stop between iterations 1 and 6."""
+    """n = 17, m = 6, hidden 3 x 200 (the register-weight rollout / two-wave Riccati / MFMA chain kernels; ls16: the
+    16-candidate line search forced for every round; ls32: the two-group form), 40 trajectories that stop between
+    iterations 1 and 6."""
     if ls16:
         monkeypatch.setenv("GMPC_LS16_SPLIT", "1")
         monkeypatch.delenv("GMPC_LS", raising=False)
+    if ls16 == "ls32":
+        monkeypatch.setenv("GMPC_LS32_SPLIT", "1")
     pb = _problem(21, out_scale=0.1, B=40, n=17, m=6, T=20, hidden=(200, 200, 200), cost_hidden=(128, 128), fout=10)
     kw = {"maxiter": 6, "obj_step_threshold": 0.0007}
-    eng, out, r64, agree = _run(pb, kw, label="headline shape" + (" ls16" if ls16 else ""), min_agree=0.5, tol=1e-3)
+    eng, out, r64, agree = _run(pb, kw, label="headline shape" + (f" {ls16 if ls16 == 'ls32' else 'ls16'}" if ls16 else ""),
+                                min_agree=0.5, tol=1e-3, tol_obj=3e-4)
     it = out["iterations"].cpu().numpy()
     assert len(set(it.tolist())) > 1
     if it.max() < 6:
