@@ -132,9 +132,8 @@ static int check_shape(const gmpc_shape* s) {
   if (s->n < 1 || s->m < 1 || s->T < 1) return fail(GMPC_EINVAL, "n, m, T must be positive");
   if (s->n > 1024 || s->m > 64)
     return fail(GMPC_EINVAL, "unsupported shape n=%d m=%d: n <= 1024 and m <= 64 are built", s->n, s->m);
-  if (s->n <= 64 && s->m > 32)
-    return fail(GMPC_EINVAL, "unsupported shape n=%d m=%d: the small-state path needs m <= 32", s->n,
-                s->m);
+  // (n <= 64 with more than 32 controls: the fused small-state kernels hold an m x m factor per lane and the gain
+  // block of a step in LDS; such shapes take the step-major pipeline of the large-state path, which is general)
   if (s->dyn_layers < 1 || s->dyn_layers > GMPC_MAX_LAYERS)
     return fail(GMPC_EINVAL, "dyn_layers must be in [2, %d]", GMPC_MAX_LAYERS);
   if (s->cost_layers < 1 || s->cost_layers > GMPC_MAX_LAYERS)
@@ -167,8 +166,9 @@ static int check_shape(const gmpc_shape* s) {
     if (s->cost_dims[l] < 1 || s->cost_dims[l] > GMPC_THREADS)
       return fail(GMPC_EINVAL, "cost hidden width must be in [1, %d]", GMPC_THREADS);
   if (s->lstm_features != 0) {
-    if (s->lstm_features != 64)
-      return fail(GMPC_EINVAL, "critic lstm_features must be 64 (4F == workgroup size)");
+    // (64: the register-weight kernels of gmpc_critic_lstm.hip / gmpc_critic.hip; other counts: k_lstm_fwd_g / _bwd_g)
+    if (s->lstm_features < 1 || s->lstm_features > 128)
+      return fail(GMPC_EINVAL, "unsupported shape: critic lstm_features = %d outside [1, 128]", s->lstm_features);
     if (s->head_layers < 1 || s->head_layers > GMPC_MAX_LAYERS)
       return fail(GMPC_EINVAL, "head_layers must be in [1, %d]", GMPC_MAX_LAYERS);
     if (s->head_dims[0] != s->lstm_features || s->head_dims[s->head_layers] != 1)
@@ -348,7 +348,7 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
   if (!rc) rc = dalloc(c, &c->lsw.counts, GMPC_LS_ROUNDS_MAX + 1 + GMPC_LS_STATS);
   if (!rc) rc = dalloc(c, &c->lsw.run, B);
   if (!rc) rc = dalloc(c, &c->lsw.objc, GMPC_LS_ITEMS * B);
-  c->big = s.n > 64;
+  c->big = s.n > 64 || s.m > 32;
   if (!c->big) {
     A_(AB, B * T * n * nm);
   } else {

@@ -494,12 +494,157 @@ void gmpc_launch_transpose(int R, int C, const float* in, float* out, hipStream_
   hipLaunchKernelGGL(k_transpose, dim3((cnt + 255) / 256), dim3(256), 0, s, R, C, in, out);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Any lstm_features F <= 128 (the reference makes it a yaml integer, critic/nn.py:11, config/gan_hyperparameters.yaml:
+// 60-65; its expert model uses 128): the kernels above and gmpc_critic_lstm.hip are built around 4 F = 256 = one
+// workgroup.  Here the 4 F gate columns and the F cell units are strided over the 256 threads; weights come from L2
+// (coalesced over the gate column / the input row), expf / tanhf activations.  4 sequences per workgroup, one float4
+// per (row, 4 sequences) in LDS.  Same saves as k_lstm_fwd (activated gates, c_t, h_{t-1}) so that the weight-gradient
+// GEMMs, the head and the wide-input path (cd.n == 0, Wcat = Wh, x Wx from xproj) are shared.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GMPC_THREADS) void k_lstm_fwd_g(int Bc, CriticDesc cd, const float* xseq, float* gates,
+                                                             float* cs, float* hp, float* hT, const float* xproj) {
+  extern __shared__ __attribute__((aligned(16))) char smem_g[];
+  const int tid = threadIdx.x;
+  const int n = cd.n, F = cd.F, T1 = cd.T1, G4 = 4 * F, K = n + F;
+  float4* act = reinterpret_cast<float4*>(smem_g);          // [n + F]: x_t, then h_{t-1}
+  float4* gbuf = act + K;                                   // [4 F] activated gates
+  float4* cst = gbuf + G4;                                  // [F] cell state
+  float* actf = reinterpret_cast<float*>(act);
+  const int s0 = blockIdx.x * 4;
+  int sq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) sq[c] = min(s0 + c, Bc - 1);
+  for (int e = tid; e < F; e += GMPC_THREADS) {
+    act[n + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    cst[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int t = 0; t < T1; ++t) {
+    for (int e = tid; e < n * 4; e += GMPC_THREADS) {
+      const int i = e >> 2, c = e & 3;
+      actf[e] = xseq[((size_t)sq[c] * T1 + t) * n + i];
+    }
+    __syncthreads();
+    for (int e = tid; e < F * 4; e += GMPC_THREADS) {       // save h_{t-1}
+      const int k = e >> 2, c = e & 3;
+      if (s0 + c < Bc) hp[((size_t)(s0 + c) * T1 + t) * F + k] = actf[(n + k) * 4 + c];
+    }
+    for (int j = tid; j < G4; j += GMPC_THREADS) {
+      const float bj = cd.b[j];
+      float4 acc[1] = {make_float4(bj, bj, bj, bj)};
+      if (xproj != nullptr) {
+        acc[0].x += xproj[((size_t)sq[0] * T1 + t) * G4 + j];
+        acc[0].y += xproj[((size_t)sq[1] * T1 + t) * G4 + j];
+        acc[0].z += xproj[((size_t)sq[2] * T1 + t) * G4 + j];
+        acc[0].w += xproj[((size_t)sq[3] * T1 + t) * G4 + j];
+      }
+      dense_rows<1>(cd.Wcat, K, G4, j, act, acc);
+      float4 v = acc[0];
+      if (j / F == 2) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+      else { v.x = sigmoidf_(v.x); v.y = sigmoidf_(v.y); v.z = sigmoidf_(v.z); v.w = sigmoidf_(v.w); }
+      gbuf[j] = v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (s0 + c < Bc) gates[((size_t)(s0 + c) * T1 + t) * G4 + j] = f4get(v, c);
+    }
+    __syncthreads();
+    for (int u = tid; u < F; u += GMPC_THREADS) {
+      const float4 ig = gbuf[u], fg = gbuf[F + u], gg = gbuf[2 * F + u], og = gbuf[3 * F + u];
+      float4 c = cst[u], h;
+      c.x = fg.x * c.x + ig.x * gg.x; c.y = fg.y * c.y + ig.y * gg.y;
+      c.z = fg.z * c.z + ig.z * gg.z; c.w = fg.w * c.w + ig.w * gg.w;
+      h.x = og.x * tanhf(c.x); h.y = og.y * tanhf(c.y); h.z = og.z * tanhf(c.z); h.w = og.w * tanhf(c.w);
+      cst[u] = c;
+      act[n + u] = h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (s0 + q < Bc) {
+          cs[((size_t)(s0 + q) * T1 + t) * F + u] = f4get(c, q);
+          if (t == T1 - 1) hT[(size_t)(s0 + q) * F + u] = f4get(h, q);
+        }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(GMPC_THREADS) void k_lstm_bwd_g(int Bc, CriticDesc cd, const float* gates, const float* cs,
+                                                             const float* dhT, float* dz, float* dxseq) {
+  extern __shared__ __attribute__((aligned(16))) char smem_g[];
+  const int tid = threadIdx.x;
+  const int n = cd.n, F = cd.F, T1 = cd.T1, G4 = 4 * F, K = n + F;
+  float4* dzb = reinterpret_cast<float4*>(smem_g);          // [4 F]
+  float4* dhb = dzb + G4;                                   // [F] dh_t
+  float4* dcb = dhb + F;                                    // [F] dc
+  const int s0 = blockIdx.x * 4;
+  int sq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) sq[c] = min(s0 + c, Bc - 1);
+  for (int u = tid; u < F; u += GMPC_THREADS) {
+    dhb[u] = make_float4(dhT[(size_t)sq[0] * F + u], dhT[(size_t)sq[1] * F + u], dhT[(size_t)sq[2] * F + u],
+                         dhT[(size_t)sq[3] * F + u]);
+    dcb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  for (int t = T1 - 1; t >= 0; --t) {
+    for (int u = tid; u < F; u += GMPC_THREADS) {
+      float zi[4], zf[4], zg[4], zo[4], dcn[4];
+      const float4 dh4 = dhb[u], dc4 = dcb[u];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const size_t gb = ((size_t)sq[c] * T1 + t) * G4;
+        const float ig = gates[gb + u], fg = gates[gb + F + u], gg = gates[gb + 2 * F + u], og = gates[gb + 3 * F + u];
+        const float ct = cs[((size_t)sq[c] * T1 + t) * F + u];
+        const float cprev = t > 0 ? cs[((size_t)sq[c] * T1 + t - 1) * F + u] : 0.f;
+        const float tc = tanhf(ct);
+        const float dh = f4get(dh4, c);
+        const float d_o = dh * tc;
+        const float dc = f4get(dc4, c) + dh * og * (1.f - tc * tc);
+        const float di = dc * gg, df_ = dc * cprev, dg = dc * ig;
+        zi[c] = di * ig * (1.f - ig); zf[c] = df_ * fg * (1.f - fg); zg[c] = dg * (1.f - gg * gg);
+        zo[c] = d_o * og * (1.f - og);
+        dcn[c] = dc * fg;
+        if (s0 + c < Bc && dz != nullptr) {
+          float* d = dz + gb;
+          d[u] = zi[c]; d[F + u] = zf[c]; d[2 * F + u] = zg[c]; d[3 * F + u] = zo[c];
+        }
+      }
+      dzb[u] = make_float4(zi[0], zi[1], zi[2], zi[3]);
+      dzb[F + u] = make_float4(zf[0], zf[1], zf[2], zf[3]);
+      dzb[2 * F + u] = make_float4(zg[0], zg[1], zg[2], zg[3]);
+      dzb[3 * F + u] = make_float4(zo[0], zo[1], zo[2], zo[3]);
+      dcb[u] = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
+    }
+    __syncthreads();
+    // [dx ; dh_{t-1}][k] = sum_j WcatT[j][k] dz[j]   (WcatT: [4 F][n + F], coalesced over k)
+    for (int k = tid; k < K; k += GMPC_THREADS) {
+      float4 acc[1] = {make_float4(0.f, 0.f, 0.f, 0.f)};
+      dense_rows<1>(cd.WcatT, G4, K, k, dzb, acc);
+      if (k < n) {
+        if (dxseq != nullptr) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (s0 + c < Bc) dxseq[((size_t)(s0 + c) * T1 + t) * n + k] = f4get(acc[0], c);
+        }
+      } else {
+        dhb[k - n] = acc[0];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 #define GMPC_CR4 1   // 4 sequences per workgroup
 
 void gmpc_launch_lstm_fwd(int Bc, const CriticDesc& cd, const float* xseq, float* gates, float* cs,
                           float* hp, float* hT, const float* xproj, hipStream_t s) {
   constexpr int R4 = GMPC_CR4;
   const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
+  if (cd.F != 64) {       // the strided form for other feature counts
+    hipLaunchKernelGGL(k_lstm_fwd_g, dim3((Bc + 3) / 4), dim3(GMPC_THREADS),
+                       ((size_t)cd.n + 6 * (size_t)cd.F) * sizeof(float4), s, Bc, cd, xseq, gates, cs, hp, hT, xproj);
+    return;
+  }
   size_t lds = ((size_t)(cd.n + cd.F) + 4 * cd.F) * R4 * sizeof(float4);
   const size_t wbytes = (size_t)(cd.n + cd.F) * 4 * cd.F * sizeof(float);
   // measured on MI355X: staging [Wx;Wh] in LDS does not pay (0.25 -> 0.28 ms): the step is bound by
@@ -527,6 +672,11 @@ void gmpc_launch_lstm_bwd(int Bc, const CriticDesc& cd, const float* gates, cons
                           const float* dhT, float* dz, float* dxseq, hipStream_t s) {
   constexpr int R4 = GMPC_CR4;
   const int grid = (Bc + 4 * R4 - 1) / (4 * R4);
+  if (cd.F != 64) {
+    hipLaunchKernelGGL(k_lstm_bwd_g, dim3((Bc + 3) / 4), dim3(GMPC_THREADS), (size_t)6 * cd.F * sizeof(float4), s, Bc,
+                       cd, gates, cs, dhT, dz, dxseq);
+    return;
+  }
   size_t lds = 2 * (size_t)(GMPC_THREADS + 128) * R4 * sizeof(float4);
   const size_t wbytes = (size_t)(cd.n + cd.F) * 4 * cd.F * sizeof(float);
   const int stage_w = 0 * (lds + wbytes <= 150 * 1024);   // no gain measured (see k_lstm_fwd)

@@ -509,17 +509,19 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_head2(int Bc, CriticDesc cd
   const int s0 = blockIdx.x * R;
   const MlpDesc& hd = cd.head;
   const int L = hd.L;
-  // layer-0 input: the final LSTM state, rows clamped
-  for (int e = tid; e < G * 256; e += GMPC_THREADS) {
-    const int g = e >> 8, k = (e & 255) >> 2, s = e & 3;
+  // layer-0 input: the final LSTM state (F0 = lstm_features values per sequence), rows clamped; the image is read in
+  // whole 16-row chunks: rows F0 .. pad16(F0) - 1 are zero
+  const int F0 = hd.dims[0], F0p = (F0 + 15) & ~15;
+  for (int e = tid; e < G * 4 * F0p; e += GMPC_THREADS) {
+    const int g = e / (4 * F0p), r = e - g * 4 * F0p, k = r >> 2, s = r & 3;
     const int row = s0 + 4 * g + s;
-    const float v = hT[(size_t)min(row, Bc - 1) * 64 + k];
+    const float v = k < F0 ? hT[(size_t)min(row, Bc - 1) * F0 + k] : 0.f;
     img[0][g * 1024 + k * 4 + s] = v;
-    if (row < Bc) acts[(size_t)row * act_stride + k] = v;
+    if (row < Bc && k < F0) acts[(size_t)row * act_stride + k] = v;
   }
   __syncthreads();
   unsigned zmask[GMPC_MAX_LAYERS];       // bit 4 g + s: relu open for row (g, s) of this thread's neuron
-  int in = 0, aoff = 64;
+  int in = 0, aoff = F0;
 #pragma unroll
   for (int lay = 0; lay < GMPC_MAX_LAYERS; ++lay) {
     zmask[lay] = 0;
@@ -675,19 +677,19 @@ __global__ __launch_bounds__(GMPC_THREADS, 2) void k_head2(int Bc, CriticDesc cd
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             const int row = s0 + 4 * g + s;
-            if (row < Bc) dhT[(size_t)row * 64 + tid] = d[g][s];
+            if (row < Bc) dhT[(size_t)row * F0 + tid] = d[g][s];
           }
       }
     }
   }
-  if (L == 1 && tid < 64) {
+  if (L == 1 && tid < F0) {
     // no hidden layer: d hT = W_last * dscore
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int row = s0 + 4 * g + s;
-        if (row < Bc) dhT[(size_t)row * 64 + tid] = wl * dsc[4 * g + s];
+        if (row < Bc) dhT[(size_t)row * F0 + tid] = wl * dsc[4 * g + s];
       }
   }
 }

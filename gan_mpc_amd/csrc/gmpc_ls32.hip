@@ -48,9 +48,13 @@ __device__ __forceinline__ f32x4_t ls32_mfma(float a, float b, f32x4_t c) {
 // float index of activation row k, candidate c
 __device__ __forceinline__ int ls32_at(int k, int c) { return (k >> 2) * LS32_GS + (k & 3) * 16 + c; }
 
-// epilogue of row block nb < 12 (the bias is in the accumulator): relu, the next layer's activations, the relu
-// bits of rows 16 nb + 4 g + i OR-ed into the candidate's mask word (mw: word 0 of this layer, 24 words per candidate)
-__device__ __forceinline__ void ls32_epilogue(f32x4_t d, int nb, float* out, unsigned* mw) {
+// epilogue of row block nb < 12 (the bias is in the accumulator): relu, the next layer's activations, and the relu
+// bits of rows 16 nb + 4 g + i as ONE BYTE of the candidate's mask image of this layer (mb: 64 bytes per candidate and
+// layer, byte 4 nb + g).  k_ls16 ORs the nibble into the mask word with an LDS atomic; an atomic is an ordered memory
+// operation to the instruction scheduler -- nothing of the other group's phase could be moved across it -- so here
+// every nibble has a byte of its own (plain stores, written anew every step: no clearing) and the state update packs
+// eight of them into the word it writes out.
+__device__ __forceinline__ void ls32_epilogue(f32x4_t d, int nb, float* out, unsigned char* mb) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   unsigned nib = 0;
 #pragma unroll
@@ -59,20 +63,34 @@ __device__ __forceinline__ void ls32_epilogue(f32x4_t d, int nb, float* out, uns
     nib |= on ? (1u << i) : 0u;
     out[(4 * nb + g) * LS32_GS + i * 16 + c] = on ? d[i] : 0.f;
   }
-  atomicOr(mw + c * 24 + (nb >> 1), nib << (16 * (nb & 1) + 4 * g));
+  mb[c * 192 + 4 * nb + g] = (unsigned char)nib;
 }
 
 // rows 192 + g (.x) and 196 + g (.y) of a hidden layer's output for candidate lane & 15 -- the B fragments of
-// k-steps 48 and 49 -- from the K-split partials of row block 12 ([4 waves][4 registers][32 lanes]); wave 0 also
-// records their relu bits (mask word 6 of the layer)
-__device__ __forceinline__ float2 ls32_tail(const float* p12, const float* bias192, unsigned* mw) {
+// k-steps 48 and 49 -- from the K-split partials of row block 12 ([4 waves][4 registers][32 lanes]); their relu bits go
+// into bytes 48 + g and 52 + g of the candidate's mask image (every wave stores the same values)
+__device__ __forceinline__ float2 ls32_tail(const float* p12, const float* bias192, unsigned char* mb) {
   const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
   const float* q = p12 + g * 32 + c;
   const float s0 = ((q[0] + q[128]) + (q[256] + q[384])) + bias192[g];
   const float s1 = ((q[16] + q[144]) + (q[272] + q[400])) + bias192[4 + g];
-  if (threadIdx.x < 64) atomicOr(mw + c * 24 + 6, ((s0 > 0.f ? 1u : 0u) << g) | ((s1 > 0.f ? 1u : 0u) << (4 + g)));
+  mb[c * 192 + 48 + g] = s0 > 0.f ? 1 : 0;
+  mb[c * 192 + 52 + g] = s1 > 0.f ? 1 : 0;
   return make_float2(fmaxf(s0, 0.f), fmaxf(s1, 0.f));
 }
+
+// Global store without a branch: lanes that are not to store get an offset past the end of the buffer resource and the
+// hardware drops their write (raw buffer, range-checked).  A phase of k_ls32 must stay ONE basic block -- an
+// `if (lane has a role) store` is an exec-mask region that the matrix-pipe instructions of the other group's phase
+// cannot be scheduled across.
+__device__ __forceinline__ void ls32_store_if(__amdgpu_buffer_rsrc_t rs, unsigned elem, unsigned bits, bool on) {
+  __builtin_amdgcn_raw_buffer_store_b32(bits, rs, on ? elem * 4u : 0xFFFFFFF0u, 0, 0);
+}
+
+// LDS store without a branch: the element index of a lane without a role is redirected to the group's dummy slot --
+// as ARITHMETIC on the index (a `cond ? p : q` store is turned back into two exec-masked stores by hipcc, and an
+// exec-mask change orders every vector and matrix instruction of the block around it)
+__device__ __forceinline__ int ls32_pick(bool on, int idx, int other) { return other + ((idx - other) & -(int)on); }
 
 // LDS layout in floats, compile-time per instantiation (every access is then one lane-dependent base register plus an
 // immediate offset; with run-time group bases hipcc kept dozens of hoisted addresses live across the horizon and
@@ -81,27 +99,26 @@ template <int K0S, int NOB>
 struct Ls32Lay {
   static constexpr int NV8 = NOB > 1 ? 8 : 0;
   static constexpr int MNX = K0S == 4 ? 64 : 128;
-  // Order: the small per-group buffers of both groups first (all inside the first 64 KB: the 16-bit immediate offset
-  // of an LDS instruction reaches them from ONE address register per thread role), then the shared tables, then the
-  // four activation buffers (two thread roles address those).  With the groups laid out one after the other every role
-  // needed a second register for group 1 and hipcc spilled ~180 loop-invariant addresses.
-  // one group's small buffers
+  // one group: its small buffers, then its two activation buffers -- ONE contiguous region per group, so that a
+  // slot of the time loop can hand the two groups to the phases as two __restrict__ pointers (see `slots` in the kernel)
   static constexpr int XCUR = 0;                                  // rows x ; u ; 0 (layer-0 input), 8 groups of 4 rows
   static constexpr int DXS = XCUR + 8 * LS32_GS;                  // x - X_nominal in the layout of xcur
   static constexpr int PART = DXS + 8 * LS32_GS;                  // [4 waves][NOB][4][64] output-layer partials
   static constexpr int P12 = PART + 4 * NOB * 256;                // [2][4 waves][4][32] block-12 partials
-  static constexpr int MASK = P12 + 2 * 4 * 4 * 32;               // [16][3 layers][8] mask words
-  static constexpr int KS = MASK + LS32_C * 24;                   // gains [16][m n] (+ slack: clamped tail reads)
+  static constexpr int MASK = P12 + 2 * 4 * 4 * 32;               // [16][3 layers][64] mask bytes (ls32_epilogue)
+  static constexpr int KS = MASK + LS32_C * 48;                   // gains [16][m n] (+ slack: clamped tail reads)
   static constexpr int KUS = KS + LS32_C * MNX + 32;              // k and U, [16][8] each
-  static constexpr int GSZ = KUS + 2 * LS32_C * 8;                // (group gi's small buffers start at gi * GSZ)
-  // shared tables
-  static constexpr int BIAS = LS32_NG * GSZ;                      // [3][208] hidden biases, [32] output bias
+  static constexpr int DUMMY = KUS + 2 * LS32_C * 8;              // [64] where the stores of lanes without a role land
+  static constexpr int ACTA = DUMMY + 64;
+  static constexpr int ACTB = ACTA + LS32_ACT;                    // (after the horizon: the stage costs [16][T])
+  static constexpr int GSZ = ACTB + LS32_ACT;                     // (group gi starts at gi * GSZ)
+  // shared tables (read-only inside the time loop), relative to TB0
+  static constexpr int TB0 = LS32_NG * GSZ;
+  static constexpr int BIAS = 0;                                  // [3][208] hidden biases, [32] output bias
   static constexpr int WXL = BIAS + 3 * LS32_ROWS + 32;           // [2 layers][52 k-steps][4 g][8]: A fragments of block 12
   static constexpr int WOL = WXL + 2 * 52 * 32;                   // [4 waves][13][64] A fragments of output block 0
   static constexpr int WOL1 = WOL + 4 * 13 * 64;                  // [4 waves][13][4 g][NV8] A fragments of output block 1
-  // activation buffers: group gi's at ACT0 + gi * 2 * LS32_ACT (A, then B; after the horizon B holds the stage costs)
-  static constexpr int ACT0 = WOL1 + 4 * 13 * 4 * NV8;
-  static constexpr int TOTAL = ACT0 + LS32_NG * 2 * LS32_ACT;
+  static constexpr int TOTAL = TB0 + WOL1 + 4 * 13 * 4 * NV8;
 };
 
 // K0S: k-steps of layer 0 (n + m <= 4 K0S); NOB: 16-row blocks of the output layer (n <= 16 NOB)
@@ -115,36 +132,42 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
   using LY = Ls32Lay<K0S, NOB>;
   constexpr int NV8 = LY::NV8;
   float* const smf = reinterpret_cast<float*>(smem_ls32);
-  float* const bias_s = smf + LY::BIAS;
-  float* const wxl = smf + LY::WXL;
-  float* const wol = smf + LY::WOL;
-  float* const wol1 = smf + LY::WOL1;
+  float* const tabs = smf + LY::TB0;
+  float* const bias_s = tabs + LY::BIAS;
+  float* const wxl = tabs + LY::WXL;
+  float* const wol = tabs + LY::WOL;
+  float* const wol1 = tabs + LY::WOL1;
   constexpr int GSZ = LY::GSZ;
   // one group's buffers
   struct Grp {
-    float *xcur, *dxs, *actA, *actB, *part, *p12, *Ks, *kUs;
-    unsigned* mask;
+    float *base, *xcur, *dxs, *actA, *actB, *part, *p12, *Ks, *kUs;
+    unsigned char* mask;
   };
-  // The group's base offsets are made opaque scalars at every call (inside the time loop): the lane-dependent part
-  // of an address is then ONE loop-invariant register shared by the two groups and the group's offset is added where
-  // the address is used.  With the offsets visible hipcc hoisted a second, group-1 copy of every address out of the
-  // loop (~170 registers) and spilled them.
-  auto grp = [&](int gi) -> Grp {
+  const int dmy = LY::DUMMY + lane;          // (float index of this lane's dummy slot inside a group's region)
+  auto grp_at = [&](float* p) -> Grp {
     Grp G;
-    int go = gi * GSZ, ga = LY::ACT0 + gi * 2 * LS32_ACT;
-    asm volatile("" : "+s"(go), "+s"(ga));
-    float* p = smf + go;
+    G.base = p;
     G.xcur = p + LY::XCUR;
     G.dxs = p + LY::DXS;
     G.part = p + LY::PART;
     G.p12 = p + LY::P12;
-    G.mask = reinterpret_cast<unsigned*>(p + LY::MASK);
+    G.mask = reinterpret_cast<unsigned char*>(p + LY::MASK);
     G.Ks = p + LY::KS;
     G.kUs = p + LY::KUS;
-    G.actA = smf + ga;
-    G.actB = G.actA + LS32_ACT;
+    G.actA = p + LY::ACTA;
+    G.actB = p + LY::ACTB;
     return G;
   };
+  // The group's base offset is made an opaque scalar at every use inside the time loop: the lane-dependent part of an
+  // address is then ONE loop-invariant register shared by the two groups and the group's offset is added where the
+  // address is used.  With the offsets visible hipcc hoisted a second, group-1 copy of every address out of the loop
+  // (~170 registers) and spilled them.
+  auto gbase = [&](int gi) -> float* {
+    int go = gi * GSZ;
+    asm volatile("" : "+s"(go));
+    return smf + go;
+  };
+  auto grp = [&](int gi) -> Grp { return grp_at(gbase(gi)); };
   __shared__ float s_alpha[NG][LS32_C], s_obj[NG][LS32_C];
   __shared__ int s_bi[NG][LS32_C], s_in[NG][LS32_C];
 
@@ -227,7 +250,6 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
   }
   // every per-group buffer starts at zero (xcur rows >= n + m, activation rows 192.., mask words, dxs = x_0 - X_0)
   for (int e = tid; e < NG * GSZ; e += LS32_THREADS) smf[e] = 0.f;
-  for (int e = tid; e < NG * 2 * LS32_ACT; e += LS32_THREADS) smf[LY::ACT0 + e] = 0.f;
   __syncthreads();
   auto BI = [&](int gi, int c) -> int { return s_bi[gi][c]; };
   auto INB = [&](int gi, int c) -> bool { return s_in[gi][c] != 0; };
@@ -287,9 +309,9 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
   };
   auto stage = [&](const Grp& G) {
 #pragma unroll
-    for (int q = 0; q < KQ; ++q)
-      if (kl + 16 * q < MN) G.Ks[kc * MN + kl + 16 * q] = pfK[q];
-    if (kl < m) { G.kUs[kc * m + kl] = pfk; G.kUs[LS32_C * 8 + kc * m + kl] = pfU; }
+    for (int q = 0; q < KQ; ++q) G.base[ls32_pick(kl + 16 * q < MN, LY::KS + kc * MN + kl + 16 * q, dmy)] = pfK[q];
+    G.base[ls32_pick(kl < m, LY::KUS + kc * m + kl, dmy)] = pfk;
+    G.base[ls32_pick(kl < m, LY::KUS + LS32_C * 8 + kc * m + kl, dmy)] = pfU;
   };
   // step 0's operands of both groups
 #pragma unroll
@@ -299,31 +321,42 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
   }
   __syncthreads();
 
-  // ================= the six phases of a group's step =================
-  auto phaseC = [&](auto gic, int t) __attribute__((always_inline)) {
-    constexpr int gi = decltype(gic)::value;
-    const Grp G = grp(gi);
-    if (con) {
-      const float* kcb = G.Ks + cc * MN + cj * n + chalf;
-      const float* dcb = G.dxs + chalf * 16 + cc;
-      float du = 0.f;
-#pragma unroll
-      for (int e = 0; e < PE; ++e) {
-        // row i = chalf + 2 e of dxs: group e / 2, row (e & 1) 2 + chalf of the group
-        const float dx = dcb[(e >> 1) * LS32_GS + (e & 1) * 32];
-        du = fmaf(kcb[2 * e], chalf + 2 * e < n ? dx : 0.f, du);
-      }
-      du += __shfl_xor(du, 1);
-      const float u = G.kUs[LS32_C * 8 + cp] + fmaf(calpha[gi], G.kUs[cp], du);
-      if (chalf == 0) {
-        if (INB(gi, cc)) a.Uc[(CI(gi, cc) * (unsigned)T + (unsigned)t) * (unsigned)m + (unsigned)cj] = u;
-        G.xcur[ls32_at(n + cj, cc)] = u;
-      }
-    }
+  // wave-uniform selects as bit masks (a `wave == k ? a : b` on a uniform condition is compiled to a scalar BRANCH,
+  // which would cut the phase's basic block in two)
+  const unsigned wm0 = wave == 0 ? 0xFFFFFFFFu : 0u, wm1 = wave == 1 ? 0xFFFFFFFFu : 0u, wm3 = wave == 3 ? 0xFFFFFFFFu : 0u;
+  auto bsel = [](unsigned mask, float a, float b) -> float {
+    return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask));
   };
-  auto phaseL0 = [&](auto gic) __attribute__((always_inline)) {
+  // candidate outputs through buffer resources (ls32_store_if); the sizes are bounded by gmpc_ls32_shape
+  const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(a.Uc, 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(a.Xc, 0, 0x7FFFFFF0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(a.maskc, 0, 0x7FFFFFF0, 0x00020000);
+  // ================= the six phases of a group's step: straight-line code, no exec-mask regions =================
+  // (gb: the group's region; tb: the shared tables -- handed down from a slot's __restrict__ parameters)
+  auto phaseC = [&](auto gic, float* gb, int t) __attribute__((always_inline)) {
     constexpr int gi = decltype(gic)::value;
-    const Grp G = grp(gi);
+    const Grp G = grp_at(gb);
+    // (lanes without a (candidate, control) pair run the same instructions on pair 0's operands and store nowhere)
+    const float* kcb = G.Ks + (con ? cc * MN + cj * n : 0) + chalf;
+    const float* dcb = G.dxs + chalf * 16 + cc;
+    float du = 0.f;
+#pragma unroll
+    for (int e = 0; e < PE; ++e) {
+      // row i = chalf + 2 e of dxs: group e / 2, row (e & 1) 2 + chalf of the group
+      const float dx = dcb[(e >> 1) * LS32_GS + (e & 1) * 32];
+      du = fmaf(kcb[2 * e], chalf + 2 * e < n ? dx : 0.f, du);
+    }
+    du += __shfl_xor(du, 1);
+    const int cq = con ? cp : 0;
+    const float u = G.kUs[LS32_C * 8 + cq] + fmaf(calpha[gi], G.kUs[cq], du);
+    const bool st = con && chalf == 0;
+    ls32_store_if(rsU, (CI(gi, cc) * (unsigned)T + (unsigned)t) * (unsigned)m + (unsigned)cj, __float_as_uint(u),
+                  st && INB(gi, cc));
+    G.base[ls32_pick(st, LY::XCUR + ls32_at(n + cj, cc), dmy)] = u;
+  };
+  auto phaseL0 = [&](float* gb, const float* tb) __attribute__((always_inline)) {
+    const Grp G = grp_at(gb);
+    const float* bias_s = tb + LY::BIAS;
     f32x4_t d[3], dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -342,18 +375,18 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
     dx = ls32_mfma(w0x[1], bx1, dx);
 #pragma unroll
     for (int r = 0; r < 3; ++r) ls32_epilogue(d[r], wave + 4 * r, G.actA, G.mask);
-    if (lane < 32) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) G.p12[(wave * 4 + i) * 32 + lane] = dx[i];
-    }
+    for (int i = 0; i < 4; ++i) G.base[ls32_pick(lane < 32, LY::P12 + (wave * 4 + i) * 32 + lane, dmy)] = dx[i];
   };
   // hidden layer hl (0: actA -> actB, partials p12[0] -> p12[1]; 1: actB -> actA, p12[1] -> p12[0])
-  auto phaseH = [&](auto gic, auto hlc) __attribute__((always_inline)) {
-    constexpr int gi = decltype(gic)::value, hl = decltype(hlc)::value;
-    const Grp G = grp(gi);
+  auto phaseH = [&](auto hlc, float* gb, const float* tb) __attribute__((always_inline)) {
+    constexpr int hl = decltype(hlc)::value;
+    const Grp G = grp_at(gb);
+    const float* bias_s = tb + LY::BIAS;
+    const float* wxl = tb + LY::WXL;
     const float* hin = hl == 0 ? G.actA : G.actB;
     float* hout = hl == 0 ? G.actB : G.actA;
-    const float2 tail = ls32_tail(G.p12 + (hl & 1) * 512, bias_s + hl * LS32_ROWS + 192, G.mask + hl * 8);
+    const float2 tail = ls32_tail(G.p12 + (hl & 1) * 512, bias_s + hl * LS32_ROWS + 192, G.mask + hl * 64);
     f32x4_t d[3], dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -384,7 +417,7 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
       if constexpr (j == 12) {
         bq[0][0] = tail.x;
         bq[0][1] = tail.y;
-        bx[0] = wave == 0 ? tail.x : wave == 1 ? tail.y : 0.f;
+        bx[0] = __uint_as_float((__float_as_uint(tail.x) & wm0) | (__float_as_uint(tail.y) & wm1));
       }
       rw_static_for<4>([&](auto ec) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value;
@@ -396,23 +429,34 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
         }
         if constexpr (e == 1) dx = ls32_mfma(ax[j & 1], bx[j & 1], dx);
       });
-      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                 // the next chunk's LDS reads
-      __builtin_amdgcn_sched_group_barrier(0x008, j < 12 ? 13 : 7, 0);   // this chunk's MFMAs
+      // between two MFMAs of the chunk: at most one LDS read, one LDS write / atomic, one buffer store and three
+      // vector instructions -- the next chunk's six fragment reads and whatever the OTHER group's phase in this
+      // basic block has ready (its LDS round trips then issue in the shadow of the matrix pipe)
+#pragma unroll
+      for (int i_ = 0; i_ < (j < 12 ? 13 : 7); ++i_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+      }
     });
 #pragma unroll
-    for (int r = 0; r < 3; ++r) ls32_epilogue(d[r], wave + 4 * r, hout, G.mask + (hl + 1) * 8);
-    if (lane < 32) {
+    for (int r = 0; r < 3; ++r) ls32_epilogue(d[r], wave + 4 * r, hout, G.mask + (hl + 1) * 64);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) G.p12[((hl + 1) & 1) * 512 + (wave * 4 + i) * 32 + lane] = dx[i];
-    }
+    for (int i = 0; i < 4; ++i)
+      G.base[ls32_pick(lane < 32, LY::P12 + ((hl + 1) & 1) * 512 + (wave * 4 + i) * 32 + lane, dmy)] = dx[i];
   };
   // output layer: k-steps 13 wave .. 13 wave + 12, partial sums through LDS; requests the operands of step t + 1
-  auto phaseO = [&](auto gic, int t) __attribute__((always_inline)) {
+  auto phaseO = [&](auto gic, float* gb, const float* tb, int t) __attribute__((always_inline)) {
     constexpr int gi = decltype(gic)::value;
-    const Grp G = grp(gi);
-    if (t + 1 < T) prefetch(gi, t + 1);
+    const Grp G = grp_at(gb);
+    const float* bias_s = tb + LY::BIAS;
+    const float* wol = tb + LY::WOL;
+    const float* wol1 = tb + LY::WOL1;
+    prefetch(gi, min(t + 1, T - 1));           // (the last step requests its own operands again: unused)
     const float* hin = G.actA;
-    const float2 tail = ls32_tail(G.p12, bias_s + 2 * LS32_ROWS + 192, G.mask + 2 * 8);
+    const float2 tail = ls32_tail(G.p12, bias_s + 2 * LS32_ROWS + 192, G.mask + 2 * 64);
     f32x4_t d[NOB];
 #pragma unroll
     for (int blk = 0; blk < NOB; ++blk) d[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -425,7 +469,8 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
         wo[NOB - 1][j] = wol1[((wave * 13 + j) * 4 + g) * NV8 + (c16 & 7)];     // (rows >= 24: copies, never read)
       }
     }
-    if (wave == 3) { bf[9] = tail.x; bf[10] = tail.y; }                           // k-steps 48, 49
+    bf[9] = bsel(wm3, tail.x, bf[9]);                                             // k-steps 48, 49
+    bf[10] = bsel(wm3, tail.y, bf[10]);
 #pragma unroll
     for (int j = 0; j < 13; ++j)
 #pragma unroll
@@ -437,60 +482,98 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
   };
   // x_{t+1} = x_t + b_L + the four partials (thread = one (coordinate, candidate) of block 0, some also of block 1);
   // this step's mask words leave, the LDS copy is cleared for the next step; the next step's operands are staged
-  auto phaseU = [&](auto gic, int t) __attribute__((always_inline)) {
+  auto phaseU = [&](auto gic, float* gb, int t) __attribute__((always_inline)) {
     constexpr int gi = decltype(gic)::value;
-    const Grp G = grp(gi);
+    const Grp G = grp_at(gb);
     const float* part = G.part;
-    float v1 = 0.f, v2 = 0.f;
-    if (on1) v1 = (((part[tid] + part[NOB * 256 + tid]) + (part[2 * NOB * 256 + tid] + part[3 * NOB * 256 + tid])) + bo1) + G.xcur[x1];
-    if (on2) v2 = (((part[pi2] + part[NOB * 256 + pi2]) + (part[2 * NOB * 256 + pi2] + part[3 * NOB * 256 + pi2])) + bo2) + G.xcur[x2];
-    const unsigned m1 = G.mask[tid], m2 = tid < LS32_C * 24 - 256 ? G.mask[tid + 256] : 0u;
-    if (on1) { G.xcur[x1] = v1; G.dxs[x1] = v1 - pfX1; }
-    if (on2) { G.xcur[x2] = v2; G.dxs[x2] = v2 - pfX2; }
+    // (coordinates past n: the same sums on in-range addresses, stored nowhere)
+    const float v1 = (((part[tid] + part[NOB * 256 + tid]) + (part[2 * NOB * 256 + tid] + part[3 * NOB * 256 + tid])) + bo1) + G.xcur[x1];
+    float v2 = 0.f;
+    if constexpr (NOB > 1)
+      v2 = (((part[pi2] + part[NOB * 256 + pi2]) + (part[2 * NOB * 256 + pi2] + part[3 * NOB * 256 + pi2])) + bo2) + G.xcur[x2];
+    // this step's mask words (thread: words tid and tid + 256 of the [16][24] block): eight nibble bytes -- or the
+    // eight bit bytes of rows 192 .. 199 -- packed
+    const bool hi = tid < LS32_C * 24 - 256;
+    auto mword = [&](int widx) -> unsigned {
+      const int c = widx / 24, w = widx - c * 24, q = w & 7;
+      const uint2 by = *reinterpret_cast<const uint2*>(G.mask + c * 192 + (w >> 3) * 64 + (q < 7 ? q : 0) * 8);
+      // nibble bytes: (b & 0xF) << 4 j; bit bytes (q == 6): (b & 1) << j
+      const unsigned lo = by.x, hi_ = by.y;
+      const unsigned nibs = (lo & 0xF) | ((lo >> 4) & 0xF0) | ((lo >> 8) & 0xF00) | ((lo >> 12) & 0xF000) |
+                            ((hi_ & 0xF) << 16) | (((hi_ >> 8) & 0xF) << 20) | (((hi_ >> 16) & 0xF) << 24) |
+                            (((hi_ >> 24) & 0xF) << 28);
+      const unsigned bits = (lo & 1) | ((lo >> 7) & 2) | ((lo >> 14) & 4) | ((lo >> 21) & 8) | ((hi_ & 1) << 4) |
+                            (((hi_ >> 8) & 1) << 5) | (((hi_ >> 16) & 1) << 6) | (((hi_ >> 24) & 1) << 7);
+      return q < 6 ? nibs : q == 6 ? bits : 0u;
+    };
+    const unsigned m1 = mword(tid), m2 = mword(hi ? tid + 256 : tid);
+    G.base[ls32_pick(on1, LY::XCUR + x1, dmy)] = v1;
+    G.base[ls32_pick(on1, LY::DXS + x1, dmy)] = v1 - pfX1;
+    if constexpr (NOB > 1) {
+      G.base[ls32_pick(on2, LY::XCUR + x2, dmy)] = v2;
+      G.base[ls32_pick(on2, LY::DXS + x2, dmy)] = v2 - pfX2;
+    }
     stage(G);
-    if (in16[gi]) {
-      const unsigned xo = (CI(gi, c16) * (unsigned)(T + 1) + (unsigned)(t + 1)) * (unsigned)n;
-      if (on1) a.Xc[xo + (unsigned)no1] = v1;
-      if (on2) a.Xc[xo + (unsigned)(16 + q2)] = v2;
-    }
+    const unsigned xo = (CI(gi, c16) * (unsigned)(T + 1) + (unsigned)(t + 1)) * (unsigned)n;
+    ls32_store_if(rsX, xo + (unsigned)no1, __float_as_uint(v1), in16[gi] && on1);
+    if constexpr (NOB > 1) ls32_store_if(rsX, xo + (unsigned)(16 + q2), __float_as_uint(v2), in16[gi] && on2);
     {
-      const int mc1 = tid / 24, mc2 = (tid + 256) / 24;
+      const int mc1 = tid / 24, mc2 = min((tid + 256) / 24, LS32_C - 1);
       const unsigned ms = (unsigned)mstride, tw = (unsigned)t * 24u;
-      if (INB(gi, mc1)) a.maskc[CI(gi, mc1) * ms + tw + (unsigned)(tid - mc1 * 24)] = m1;
-      if (tid < LS32_C * 24 - 256 && INB(gi, mc2)) a.maskc[CI(gi, mc2) * ms + tw + (unsigned)(tid + 256 - mc2 * 24)] = m2;
+      ls32_store_if(rsM, CI(gi, mc1) * ms + tw + (unsigned)(tid - mc1 * 24), m1, INB(gi, mc1));
+      ls32_store_if(rsM, CI(gi, mc2) * ms + tw + (unsigned)(tid + 256 - mc2 * 24), m2, hi && INB(gi, mc2));
     }
-    G.mask[tid] = 0u;
-    if (tid < LS32_C * 24 - 256) G.mask[tid + 256] = 0u;
   };
 
+  // (a slot is one scheduling region: without the fences the scheduler sees slots 4 .. 6 -- one basic block, barriers
+  // do not end one -- as a single region of 1,700 instructions and the group solver takes minutes)
+#define LS32_SLOT_END() do { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); } while (0)
   using X_ = std::integral_constant<int, 0>;
   using Y_ = std::integral_constant<int, 1>;
   using H1_ = std::integral_constant<int, 0>;
   using H2_ = std::integral_constant<int, 1>;
   // ================= the horizon: group Y four phases behind group X =================
+  // A slot = one phase of each group in ONE basic block.  The two groups and the tables come in as __restrict__
+  // parameters: inlined, that becomes scoped no-alias information on every LDS access of the slot -- without it the
+  // opaque group offsets leave the compiler unable to tell group X's stores from group Y's loads, and the latency
+  // chain of one group is pinned behind the epilogue stores of the other's matrix-pipe phase.
+  auto slot1 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
+      __attribute__((always_inline)) { phaseC(X_{}, gx, t); phaseO(Y_{}, gy, tb, t - 1); };
+  auto slot2 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
+      __attribute__((always_inline)) { phaseL0(gx, tb); phaseU(Y_{}, gy, t - 1); };
+  auto slot3 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
+      __attribute__((always_inline)) { phaseH(H1_{}, gx, tb); phaseC(Y_{}, gy, t); };
+  auto slot4 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb)
+      __attribute__((always_inline)) { phaseH(H2_{}, gx, tb); phaseL0(gy, tb); };
+  auto slot5 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
+      __attribute__((always_inline)) { phaseH(H1_{}, gy, tb); phaseO(X_{}, gx, tb, t); };
+  auto slot6 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
+      __attribute__((always_inline)) { phaseH(H2_{}, gy, tb); phaseU(X_{}, gx, t); };
   for (int t = 0; t < T; ++t) {
-    phaseC(X_{}, t);
-    if (t > 0) phaseO(Y_{}, t - 1);
-    __syncthreads();
-    phaseL0(X_{});
-    if (t > 0) phaseU(Y_{}, t - 1);
-    __syncthreads();
-    phaseH(X_{}, H1_{});
-    phaseC(Y_{}, t);
-    __syncthreads();
-    phaseH(X_{}, H2_{});
-    phaseL0(Y_{});
-    __syncthreads();
-    phaseH(Y_{}, H1_{});
-    phaseO(X_{}, t);
-    __syncthreads();
-    phaseH(Y_{}, H2_{});
-    phaseU(X_{}, t);
-    __syncthreads();
+    if (t > 0) {
+      slot1(gbase(0), gbase(1), tabs, t);
+    } else {
+      phaseC(X_{}, gbase(0), t);
+    }
+    LS32_SLOT_END();
+    if (t > 0) {
+      slot2(gbase(0), gbase(1), tabs, t);
+    } else {
+      phaseL0(gbase(0), tabs);
+    }
+    LS32_SLOT_END();
+    slot3(gbase(0), gbase(1), tabs, t);
+    LS32_SLOT_END();
+    slot4(gbase(0), gbase(1), tabs);
+    LS32_SLOT_END();
+    slot5(gbase(0), gbase(1), tabs, t);
+    LS32_SLOT_END();
+    slot6(gbase(0), gbase(1), tabs, t);
+    LS32_SLOT_END();
   }
-  phaseO(Y_{}, T - 1);
+  phaseO(Y_{}, gbase(1), tabs, T - 1);
   __syncthreads();
-  phaseU(Y_{}, T - 1);
+  phaseU(Y_{}, gbase(1), T - 1);
   __syncthreads();
 
   // ---- stage costs: 4 lanes per (candidate, step) pair, 64 pairs per sweep; summed per candidate in step order
@@ -533,7 +616,7 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
   }
   __syncthreads();
   if (tid < NG * LS32_C) {
-    const float* cst = smf + LY::ACT0 + (tid >> 4) * 2 * LS32_ACT + LS32_ACT + (tid & 15) * T;      // group's actB
+    const float* cst = smf + (tid >> 4) * GSZ + LY::ACTB + (tid & 15) * T;      // group's actB
     float acc = 0.f;
     for (int t = 0; t < T; ++t) acc += cst[t];
     s_obj[tid >> 4][tid & 15] = acc;

@@ -818,8 +818,10 @@ __global__ __launch_bounds__(128) void k_riccati_w2h(RiccatiArgs a, const float*
 #pragma unroll
         for (int i = j + 1; i < m; ++i) {
           if (piv == i) {
+            // (columns >= j only: the multipliers already stored in columns < j belong to the row POSITIONS, because
+            // the right-hand-side columns below apply swap j and elimination j in turn, like the serial elimination)
 #pragma unroll
-            for (int c = 0; c < m; ++c) { const float t_ = Lr[j][c]; Lr[j][c] = Lr[i][c]; Lr[i][c] = t_; }
+            for (int c = j; c < m; ++c) { const float t_ = Lr[j][c]; Lr[j][c] = Lr[i][c]; Lr[i][c] = t_; }
           }
         }
         const float d = Lr[j][j];

@@ -110,6 +110,8 @@ class Engine:
         self.n, self.m, self.T = int(n), int(m), int(T)
         self.nx = int(x_size) if dyn_lstm else int(n)      # x part of xc: goals / critic / expert columns
         self.max_batch = int(max_batch)
+        # the step-major ("large-state") pipeline: n > 64, or more than 32 controls; it keeps ONE step of Jacobians
+        self.big = self.n > 64 or self.m > 32
         self.dyn_count = self.lib.gmpc_param_count(C.byref(self.shape), 0)
         self.cost_count = self.lib.gmpc_param_count(C.byref(self.shape), 1)
         self.critic_count = self.lib.gmpc_param_count(C.byref(self.shape), 2) if lstm_features else 0
@@ -178,7 +180,7 @@ class Engine:
         if out is None:
             out = dict(K=self.new(B, T, m, n), k=self.new(B, T, m), grad=self.new(B, T, m),
                        adjoints=self.new(B, T + 1, n))
-            if n <= 64:   # the large-state pass is step-major and never holds all T Jacobians
+            if not self.big:   # the large-state pass is step-major and never holds all T Jacobians
                 out["AB"] = self.new(B, T, n, n + m)
         fn = self.lib.gmpc_lqr_backward_after_rollout if after_rollout else self.lib.gmpc_lqr_backward
         _lib.check(fn(self.ctx, B, _ptr(X), _ptr(U), _ptr(goal), _ptr(out["K"]), _ptr(out["k"]),

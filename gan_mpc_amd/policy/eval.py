@@ -26,7 +26,7 @@ class LqrBlock:
     @property
     def shape(self):
         e = self._engine
-        full = (self._batch, e.T, e.n, e.n + e.m) if e.n <= 64 else (self._batch, e.n, e.n + e.m)
+        full = (self._batch, e.T, e.n, e.n + e.m) if not e.big else (self._batch, e.n, e.n + e.m)
         return full if self._index is None else full[1:]
 
     def __getitem__(self, i):
@@ -38,7 +38,7 @@ class LqrBlock:
 
     def tensor(self):
         e = self._engine
-        full = (self._batch, e.T, e.n, e.n + e.m) if e.n <= 64 else (self._batch, e.n, e.n + e.m)
+        full = (self._batch, e.T, e.n, e.n + e.m) if not e.big else (self._batch, e.n, e.n + e.m)
         t = e.debug_buffer(5, full)
         return t if self._index is None else t[self._index]
 

@@ -45,6 +45,10 @@ SHAPES = {
     # spare (big_solve_mfma<8>: m = 30 of 32; <16>: m = 41 of 64)
     "big-m30": (72, 30, 4, 3, dict(dyn_hidden=(96, 80), cost_hidden=(48,), cost_fout=8, out_scale=0.3)),
     "big-m41": (90, 41, 3, 3, dict(dyn_hidden=(96, 80), cost_hidden=(48,), cost_fout=8, out_scale=0.3)),
+    # n <= 64 with more than 32 controls (round 4): the step-major pipeline as well (the fused small-state kernels
+    # are built for m <= 32)
+    "m40-n24": (24, 40, 5, 4, dict(dyn_hidden=(64, 48), cost_hidden=(32,), cost_fout=6, out_scale=0.3)),
+    "m64-n10": (10, 64, 4, 3, dict(dyn_hidden=(96, 80), cost_hidden=(24,), cost_fout=5, out_scale=0.3)),
     "c4-humanoid": (376, 17, 4, 3, dict(out_scale=0.3)),
     "c5-synthetic": (1024, 64, 3, 2, dict(out_scale=0.3)),
     # last hidden width h < n / 2: the large-state pass runs on the low-rank form A = I + W_L^T Vx^T (gmpc_large.hip)
@@ -129,7 +133,7 @@ def test_lqr_backward(name, after_rollout):
     AB32 = np.concatenate([lqr32[5][:, :T], lqr32[6][:, :T]], -1)
     AB64 = np.concatenate([lqr64[5][:, :T], lqr64[6][:, :T]], -1)
     ok_s = ~bad_s
-    if n <= 64:
+    if not eng.big:
         AB = out["AB"].cpu().numpy()
         gu.assert_parity("AB", AB[ok_s], AB32[ok_s], AB64[ok_s])
     else:   # step-major pass: only the Jacobians of the last processed step (t = 0) are left
@@ -165,6 +169,38 @@ def test_critic_loss_grad(name, head):
     gu.assert_parity("critic loss", ls.cpu().numpy() / (2 * B), l32, l64)
     gu.assert_parity("critic grad", gs.cpu().numpy() / (2 * B), gu.pack_grads_critic(g32),
                      gu.pack_grads_critic(g64))
+
+
+@pytest.mark.parametrize("F,n,head,Bq", [(32, 17, (64, 64), 11), (128, 17, (256,), 9), (24, 5, (), 6), (128, 300, (32,), 5)])
+def test_critic_other_lstm_feature_counts(F, n, head, Bq):
+    """critic.lstm.lstm_features is a yaml integer in the reference (critic/nn.py:10-14, config/
+    gan_hyperparameters.yaml:60-65; its expert model uses 128): 64 runs the register-weight kernels, every other count
+    up to 128 the strided k_lstm_fwd_g / k_lstm_bwd_g -- the critic step (loss, BPTT, weight gradients), the score and
+    its input gradient (the generator loss's path), ragged batch; (128, 300): the wide-input form, x Wx as a GEMM."""
+    m, T = 3, 9
+    pb = orc.make_problem(n, m, T, Bq, seed=40 + F, dtype=np.float32, dyn_hidden=(16, 16), cost_hidden=(12,), cost_fout=4,
+                          lstm_features=F, head_hidden=head, bias_scale=0.1)
+    pb64 = orc.cast_problem(pb, np.float64)
+    gu.set_config(f"critic F={F} n={n} T={T} B={Bq} head={head}")
+    eng = gu.engine_for(pb)
+    d = eng.to_dev
+    try:
+        xseq = np.concatenate([pb["true_seq"], pb["goal"]], 0)
+        rng = np.random.default_rng(F)
+        label = np.where(rng.random(2 * Bq) > 0.5, 1.0, -1.0).astype(np.float32)
+        crit = d(gu.critic_flat(pb))
+        ls, gs = eng.critic_loss_grad(d(xseq), d(label), crit)
+        l32, g32 = orc.critic_loss_and_grad(pb["critic"], xseq, label)
+        l64, g64 = orc.critic_loss_and_grad(pb64["critic"], xseq.astype(np.float64), label.astype(np.float64))
+        gu.assert_parity("critic loss", ls.cpu().numpy() / (2 * Bq), l32, l64)
+        gu.assert_parity("critic grad", gs.cpu().numpy() / (2 * Bq), gu.pack_grads_critic(g32), gu.pack_grads_critic(g64))
+        score, dx = eng.critic_score_vjp(d(pb["true_seq"]), crit)
+        gu.assert_parity("score", score.cpu().numpy(), orc.critic_forward(pb["critic"], pb["true_seq"]),
+                         orc.critic_forward(pb64["critic"], pb["true_seq"].astype(np.float64)))
+        gu.assert_parity("dscore/dx", -dx.cpu().numpy(), orc.generator_loss_grad_x(pb["critic"], pb["true_seq"]),
+                         orc.generator_loss_grad_x(pb64["critic"], pb["true_seq"].astype(np.float64)))
+    finally:
+        eng.close()
 
 
 def test_critic_loss_grad_odd_row_count():
@@ -218,7 +254,7 @@ def test_adam_clip_step():
 
 
 @pytest.mark.parametrize("name", ["tiny-ragged", "trained-like", "big-70", "rw-wide-io", "rw-ragged", "rw-one-step",
-                                  "rw-128", "rw-64",
+                                  "rw-128", "rw-64", "m40-n24",
                                   "dynl-small", "dynl-two-layers", "dynl-big", "lowrank-2h"])
 def test_ilqr_single_iteration_teacher_forced(name):
     """maxiter=1 from the same start: tvlqr + line search + re-linearisation, one iteration."""
@@ -374,7 +410,7 @@ def test_gain_solve_matrix_pipe_against_vector_form(name, monkeypatch):
 @pytest.mark.parametrize("name,loss_kind", [("trained-like", 0), ("trained-like", 1), ("big-70", 0),
                                             ("big-70", 1), ("c4-humanoid", 0), ("dynl-small", 0),
                                             ("dynl-small", 1), ("dynl-big", 0), ("dynl-big", 1),
-                                            ("lowrank-1h", 0), ("lowrank-2h", 1), ("lowrank-3h", 0)])
+                                            ("lowrank-1h", 0), ("lowrank-2h", 1), ("lowrank-3h", 0), ("m40-n24", 0)])
 def test_bilevel_grad(name, loss_kind):
     """a8-a11 at the lower-level solution the GPU found.  The Hessian solve is ill-conditioned
     (forward error = cond(A) x backward error), so H is checked by its residual A H - B in fp64;
@@ -510,7 +546,9 @@ def test_unsupported_shape_fails_loudly():
     with pytest.raises(GmpcError, match="unsupported shape"):
         Engine(1100, 17, 5, [1117, 200, 200, 200, 1100], [1100, 128, 128, 10], max_batch=2)
     with pytest.raises(GmpcError, match="unsupported shape"):
-        Engine(40, 40, 5, [80, 64, 40], [40, 32, 8], max_batch=2)
+        Engine(40, 65, 5, [105, 64, 40], [40, 32, 8], max_batch=2)
+    with pytest.raises(GmpcError, match="unsupported shape"):       # critic lstm_features above 128
+        Engine(5, 2, 5, [7, 16, 5], [5, 8, 4], max_batch=2, lstm_features=192, head_dims=[192, 1])
 
 
 def test_nan_trajectory_follows_the_trajax_rules_and_is_isolated():
