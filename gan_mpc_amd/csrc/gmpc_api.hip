@@ -254,6 +254,7 @@ struct gmpc_ctx {
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[GMPC_PROF_SLOTS];
   const char* lin_kernel = "";      // kernel the last Jacobian chain ran on (gmpc_profile_kernel_name)
+  char lin_kernel_buf[96] = "";     // name of the chain instantiation this ctx launched last (copied at launch time)
   hipEvent_t lin_event = nullptr;   // caller's event, recorded after the Jacobian chain (gmpc_set_linearize_event)
   // the critic's head weight gradients run beside the BPTT sweep (critic_forward_backward): a context-owned side
   // stream forked after k_head2 and joined behind the sweep
@@ -388,20 +389,36 @@ extern "C" int gmpc_create(const gmpc_shape* shape, int max_batch, int device, g
       // each other down by what the overlap saves, C5 1.980 vs 1.984 s; GMPC_BIG_PIPELINE=2 turns it on there)
       const bool lr_too = e != nullptr && e[0] == '2';
       if (!c->dynl && !(e != nullptr && e[0] == '0') && (c->bw.h == 0 || lr_too)) {
-        if (c->bw.h > 0) {
-          const size_t hl = c->bw.h;
-          B_(Vt2, B * hl * nm + pad);
-          B_(Sm, B * hl * hl + pad);
-        } else {
-          B_(ABt2, B * n * nm + pad);
-        }
+        // (the second copy and the side stream are an optimisation: when any of them cannot be had -- the copy is
+        // B n (n + m) floats, 4.5 GB at n = 1024 -- the pass runs on one stream with one buffer)
         if (!rc) {
-          bool ok = hipStreamCreateWithFlags(&c->bw.side, hipStreamNonBlocking) == hipSuccess;
+          const size_t cnt2 = c->bw.h > 0 ? B * (size_t)c->bw.h * nm + pad : B * n * nm + pad;
+          const size_t cnt3 = c->bw.h > 0 ? B * (size_t)c->bw.h * c->bw.h + pad : 0;
+          float *p2 = nullptr, *p3 = nullptr;
+          bool ok = hipMalloc(reinterpret_cast<void**>(&p2), cnt2 * sizeof(float)) == hipSuccess;
+          if (ok && cnt3) ok = hipMalloc(reinterpret_cast<void**>(&p3), cnt3 * sizeof(float)) == hipSuccess;
+          ok = ok && hipMemset(p2, 0, cnt2 * sizeof(float)) == hipSuccess;
+          if (ok && p3) ok = hipMemset(p3, 0, cnt3 * sizeof(float)) == hipSuccess;
+          ok = ok && hipStreamCreateWithFlags(&c->bw.side, hipStreamNonBlocking) == hipSuccess;
           ok = ok && hipEventCreateWithFlags(&c->bw.ev_start, hipEventDisableTiming) == hipSuccess;
           for (int i = 0; i < 2 && ok; ++i)
             ok = hipEventCreateWithFlags(&c->bw.ev_ready[i], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&c->bw.ev_free[i], hipEventDisableTiming) == hipSuccess;
-          if (!ok) rc = fail(GMPC_EHIP, "side stream / events of the large-state pass");
+          if (ok) {
+            c->allocs.push_back(p2);
+            if (p3) c->allocs.push_back(p3);
+            if (c->bw.h > 0) { c->bw.Vt2 = p2; c->bw.Sm = p3; } else { c->bw.ABt2 = p2; }
+          } else {
+            (void)hipGetLastError();
+            if (p2) (void)hipFree(p2);
+            if (p3) (void)hipFree(p3);
+            if (c->bw.side) { (void)hipStreamDestroy(c->bw.side); c->bw.side = nullptr; }
+            if (c->bw.ev_start) { (void)hipEventDestroy(c->bw.ev_start); c->bw.ev_start = nullptr; }
+            for (int i = 0; i < 2; ++i) {
+              if (c->bw.ev_ready[i]) { (void)hipEventDestroy(c->bw.ev_ready[i]); c->bw.ev_ready[i] = nullptr; }
+              if (c->bw.ev_free[i]) { (void)hipEventDestroy(c->bw.ev_free[i]); c->bw.ev_free[i] = nullptr; }
+            }
+          }
         }
       }
     }
@@ -672,7 +689,8 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     } else if (force == 0 && (rc_regs = gmpc_launch_linearize_regs(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks,
                                                                    active, AB, 1, 0, s, c->lin_event)) >= 0) {
       // (rc 1: the caller's event sits between the chain's full rounds and its ragged last round)
-      c->lin_kernel = gmpc_linearize_regs_last_name();
+      snprintf(c->lin_kernel_buf, sizeof(c->lin_kernel_buf), "%s", gmpc_linearize_regs_last_name());
+      c->lin_kernel = c->lin_kernel_buf;
       lin_event_done = rc_regs == 1;
     } else if (force == 2 ||
         gmpc_launch_linearize_mfma(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, active, AB, 1, 0,
@@ -867,6 +885,11 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     HIP_TRY(hipEventCreateWithFlags(&c->crit_join, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&c->crit_tr, hipEventDisableTiming));
   }
+  // (an error return between a fork onto the side stream and its join must not leave work in flight there)
+  struct SideGuard {
+    hipStream_t st = nullptr;
+    ~SideGuard() { if (st) { (void)hipStreamSynchronize(st); (void)hipGetLastError(); } }
+  } side_guard;
   CriticDesc cd;
   TRY(bind_critic(c, critic, cd, s, !side_on));
   const bool tr_side = side_on && gmpc_lstm2_supported(cd);
@@ -874,6 +897,7 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
   if (tr_side) {
     HIP_TRY(hipEventRecord(c->crit_fork, s));
     HIP_TRY(hipStreamWaitEvent(c->crit_side, c->crit_fork, 0));
+    side_guard.st = c->crit_side;
     gmpc_launch_mlp_transpose_all(cd.head, c->crit_side);
     HIP_TRY(hipEventRecord(c->crit_tr, c->crit_side));
   }
@@ -910,7 +934,10 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     }
     gmpc_launch_lstm_fwd(Bc, cr, xseq, c->gates, c->cs, c->hp, c->hT, widein ? c->xproj : nullptr, s);
   }
-  if (tr_side) HIP_TRY(hipStreamWaitEvent(s, c->crit_tr, 0));
+  if (tr_side) {
+    HIP_TRY(hipStreamWaitEvent(s, c->crit_tr, 0));
+    side_guard.st = nullptr;        // joined
+  }
   {
     ProfScope ps(c, PROF_HEAD, s);
     gmpc_launch_head2(Bc, cd, loss_kind, c->hT, label, c->cscore, c->closs, c->hacts, c->hdels, c->plast, c->dhT,
@@ -923,6 +950,7 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
     HIP_TRY(hipStreamWaitEvent(c->crit_side, c->crit_fork, 0));
     sw = c->crit_side;
     forked = true;
+    side_guard.st = c->crit_side;
   }
   float* gWx0 = grad_sum;
   if (gen2 && (dxseq || want_wgrad)) {
@@ -1006,6 +1034,7 @@ static int critic_forward_backward(gmpc_ctx* c, int Bc, const float* xseq, const
   if (forked) {
     HIP_TRY(hipEventRecord(c->crit_join, sw));
     HIP_TRY(hipStreamWaitEvent(s, c->crit_join, 0));
+    side_guard.st = nullptr;        // joined
   }
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1474,7 +1503,7 @@ extern "C" int gmpc_bgemm_tn(gmpc_ctx* c, int batch, int M, int N, int K, const 
 extern "C" long gmpc_linesearch_candidates(gmpc_ctx* c) {
   if (!c) return -1;
   int v = 0;
-  if (hipSetDevice(c->device) != hipSuccess ||
+  if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
       hipMemcpy(&v, c->lsw.counts + GMPC_LS_ROUNDS_MAX, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
   return v;
@@ -1484,6 +1513,7 @@ extern "C" int gmpc_linesearch_stats(gmpc_ctx* c, long* out, int n) {
   if (!c || !out) return fail(GMPC_EINVAL, "ctx / out is null");
   int v[GMPC_LS_STATS];
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());      // (streams created non-blocking are not ordered against a null-stream copy)
   HIP_TRY(hipMemcpy(v, c->lsw.counts + GMPC_LS_ROUNDS_MAX + 1, sizeof(v), hipMemcpyDeviceToHost));
   for (int i = 0; i < n; ++i) out[i] = i < GMPC_LS_STATS ? v[i] : 0;
   return 0;

@@ -1506,11 +1506,19 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
       rc_side = -1;
     }
   };
+  // event / wait failures: a missed wait would be a silent race on the Jacobian copies, so they end the pass; on any
+  // error after the fork the caller's stream first joins the side stream (nothing is left in flight on it)
+  auto ev = [&](hipError_t e) { if (e != hipSuccess) rc_side = -1; };
+  auto bail = [&]() -> int {
+    if (pipe) (void)hipStreamSynchronize(w.side);
+    (void)hipGetLastError();
+    return -1;
+  };
   if (pipe) {
-    (void)hipEventRecord(w.ev_start, s);                 // the side stream starts behind the caller's earlier work
-    (void)hipStreamWaitEvent(w.side, w.ev_start, 0);
+    ev(hipEventRecord(w.ev_start, s));                   // the side stream starts behind the caller's earlier work
+    ev(hipStreamWaitEvent(w.side, w.ev_start, 0));
     jacobians(T - 1, w.side);
-    (void)hipEventRecord(w.ev_ready[(T - 1) & 1], w.side);
+    ev(hipEventRecord(w.ev_ready[(T - 1) & 1], w.side));
   }
   for (int t = T - 1; t >= 0; --t) {
     const float* A = ABc[t & 1];
@@ -1524,14 +1532,14 @@ int gmpc_big_backward(const BigWork& w, int B, const MlpDesc& dyn, const LinPad&
     // products and k_big_step alone)
     auto start_next = [&]() {
       if (!pipe || t == 0) return;
-      (void)hipEventRecord(w.ev_free[(t - 1) & 1], s);      // (the copy's last reader was step t + 1; this point is later)
-      (void)hipStreamWaitEvent(w.side, w.ev_free[(t - 1) & 1], 0);
+      ev(hipEventRecord(w.ev_free[(t - 1) & 1], s));        // (the copy's last reader was step t + 1; this point is later)
+      ev(hipStreamWaitEvent(w.side, w.ev_free[(t - 1) & 1], 0));
       jacobians(t - 1, w.side);
-      (void)hipEventRecord(w.ev_ready[(t - 1) & 1], w.side);
+      ev(hipEventRecord(w.ev_ready[(t - 1) & 1], w.side));
     };
-    if (pipe) (void)hipStreamWaitEvent(s, w.ev_ready[t & 1], 0);
+    if (pipe) ev(hipStreamWaitEvent(s, w.ev_ready[t & 1], 0));
     else if (dl == nullptr) jacobians(t, s);
-    if (rc_side != 0) return -1;
+    if (rc_side != 0) return bail();
     if (lowrank) {
       // the factors V_t^T (above), then the n^3 products through them (see big_lowrank_factors)
       // Y = W_L P, S = W_L P W_L^T = W_L Y^T, then with Z = Y + S Vx^T / 2:

@@ -240,7 +240,7 @@ def test_headline_shape_heterogeneous_stops(ls16, monkeypatch):
     pb = _problem(21, out_scale=0.1, B=40, n=17, m=6, T=20, hidden=(200, 200, 200), cost_hidden=(128, 128), fout=10)
     kw = {"maxiter": 6, "obj_step_threshold": 0.0007}
     eng, out, r64, agree = _run(pb, kw, label="headline shape" + (f" {ls16 if ls16 == 'ls32' else 'ls16'}" if ls16 else ""),
-                                min_agree=0.5, tol=1e-3, tol_obj=3e-4)
+                                min_agree=0.65, tol=1e-3, tol_obj=3e-4)      # (27 of the 40 trajectories are decided)
     it = out["iterations"].cpu().numpy()
     assert len(set(it.tolist())) > 1
     if it.max() < 6:
