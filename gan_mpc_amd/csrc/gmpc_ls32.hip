@@ -700,10 +700,13 @@ bool gmpc_ls32_shape(const TrajArgs& a) {
   return a.n <= 24 && a.m * a.n <= (k0s <= 4 && a.n <= 16 ? 64 : 128) && ls32_lds(a.n, a.m) <= LS32_LDS_MAX &&
          LS32_C * a.T <= LS32_ACT && items * (a.T + 1) * a.n < (1L << 31) && items * a.T * 3 * GMPC_MW < (1L << 31);
 }
-// work lists of at least this many candidates are k_ls32's (more than one pass of k_ls16 over the chip)
+// work lists of at least this many candidates are k_ls32's.  OFF unless GMPC_LS32_SPLIT is set (the tests set it to
+// 1): measured in round 4 (profiles/EXPERIMENTS.md), the 8192 candidates of a first round take one pass of this kernel
+// 0.93 ms in its plain two-group form -- what two passes of k_ls16 take -- and 1.2 ms in the present, branch-free form
+// (hipcc spills 54 registers of the 512 into scratch inside the time loop), so k_ls16 keeps every long work list.
 int gmpc_ls32_split() {
   const char* e = getenv("GMPC_LS32_SPLIT");
-  return e != nullptr && atoi(e) > 0 ? atoi(e) : 4097;
+  return e != nullptr && atoi(e) > 0 ? atoi(e) : 0;
 }
 
 template <int K0S, int NOB>

@@ -525,7 +525,7 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
   if (rw) a.aw = traj_aw(a.n, a.m, a.dyn, &a.cost);
   const bool ls16 = rw && gmpc_ls16_shape(a);
   a.ls_split = ls16 ? gmpc_ls16_split() : 0;
-  const bool ls32 = ls16 && gmpc_ls32_shape(a) && (long)a.B * GMPC_LS_ITEMS >= gmpc_ls32_split();
+  const bool ls32 = ls16 && gmpc_ls32_split() > 0 && gmpc_ls32_shape(a) && (long)a.B * GMPC_LS_ITEMS >= gmpc_ls32_split();
   a.ls32_split = ls32 ? gmpc_ls32_split() : 0;
   const size_t lds = eval ? 0 : rw ? gmpc_traj_rw_lds(a) : traj_lds(a);
   static bool attr = false;

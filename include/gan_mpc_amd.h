@@ -258,23 +258,30 @@ int gmpc_bgemm_tn(gmpc_ctx* ctx, int batch, int M, int N, int K, const float* X,
                   float* C, float alpha, float beta, void* stream);
 
 /* Number of candidate rollouts (trajectory, step size) the line searches of the last gmpc_ilqr_solve
- * evaluated -- the work count behind bench.py's secondary roofline.  Synchronises the device. */
+ * evaluated -- the work count behind bench.py's secondary roofline.  Synchronises the whole device
+ * (hipDeviceSynchronize). */
 long gmpc_linesearch_candidates(gmpc_ctx* ctx);
 
 /* Counters of the line searches of the last gmpc_ilqr_solve, `n` <= 64 values: out[k], k = 0..15 = line searches
  * that accepted the step alpha_0 / 2^k (trajax line_search_ddp as called from policy/optimizers.py:19), out[16] =
- * line searches that ran out of step sizes, out[24 + r] = candidate rollouts of speculative round r.  Diagnostic
- * (bench.py reports it); synchronises the device. */
+ * line searches that ran out of step sizes, out[17] = the deepest halving accepted since the solve began, out[24 + r] =
+ * candidate rollouts of speculative round r.  Diagnostic (bench.py reports it); synchronises the whole device
+ * (hipDeviceSynchronize: streams created non-blocking included). */
 int gmpc_linesearch_stats(gmpc_ctx* ctx, long* out, int n);
 
 /* Stream overlap hook.  `hip_event` (a hipEvent_t, or NULL to clear) is recorded on the backward pass's stream
- * right after the Jacobian chain of gmpc_lqr_backward(_after_rollout) / of every iteration of gmpc_ilqr_solve has
- * been enqueued, i.e. before the terminal quadratisation and the Riccati sweep (large-state path: before the
- * step-major pipeline).  A caller that runs independent work on a second stream -- the critic step of the GAN
- * loop: reference gan/runner.py:120-168 has no data dependence between it and the policy's backward pass --
- * makes that stream wait for the event: the work then shares the chip with the Riccati sweep (one wavefront
- * per trajectory: three quarters of the wave slots are free) instead of taking workgroup slots from the
- * matrix-core-bound Jacobian chain.  The event must outlive its use. */
+ * behind the Jacobian chain of gmpc_lqr_backward(_after_rollout) / of every iteration of gmpc_ilqr_solve.  Order of
+ * the small-state pass since round 3: terminal quadratisation, Jacobian chain, EVENT, Riccati sweep (the terminal
+ * quadratisation needs X only and runs first, so that the sweep is the launch right behind the chain;
+ * GMPC_TERMINAL_FIRST=0 restores chain, event, terminal, sweep).  Large-state path: the event is recorded at the top
+ * of the pass, before the terminal quadratisation and the step-major pipeline.  With GMPC_LIN_SPLIT=<percent> the
+ * chain's ragged last round is a launch of its own and the event sits between the two launches -- the waiter then
+ * starts while the last Jacobians are still being written, so it must not read them (bench.py's critic step does not);
+ * off by default (measured, no gain).  A caller that runs independent work on a second stream -- the critic step of
+ * the GAN loop: reference gan/runner.py:120-168 has no data dependence between it and the policy's backward pass --
+ * makes that stream wait for the event: the work then shares the chip with the Riccati sweep (two wavefronts per
+ * trajectory: most wave slots and registers are free) instead of taking workgroup slots from the matrix-core-bound
+ * Jacobian chain.  The event must outlive its use. */
 int gmpc_set_linearize_event(gmpc_ctx* ctx, void* hip_event);
 
 /* Optional per-kernel timing with HIP events recorded on the launch stream around each kernel
@@ -286,7 +293,8 @@ int gmpc_profile_enable(gmpc_ctx* ctx, int on);
 int gmpc_profile_read(gmpc_ctx* ctx, int slot, double* total_ms, int* count);
 /* Name of the kernel the slot's last launch ran on, as it appears in a rocprofv3 kernel trace (slot 1, the
  * Jacobian chain: the instantiation the shape selected, e.g. "k_linearize_regs<6, 100, 8, false>"); "" for slots
- * that always run the same kernel.  Static storage, valid until the next launch. */
+ * that always run the same kernel.  The string lives in the context (copied when the chain is launched): valid until
+ * the context's next backward pass or gmpc_destroy. */
 const char* gmpc_profile_kernel_name(gmpc_ctx* ctx, int slot);
 
 /* Device pointers into the ctx's solution of the last gmpc_ilqr_solve / gmpc_bilevel_grad (valid

@@ -5,12 +5,12 @@ V=$1
 R=$PWD
 O=$R/gpurun_out/prof_$V   # copy what is to be kept into profiles/ afterwards
 mkdir -p $O
-python bench.py > $O/bench.json
+python bench.py --steps 20 --warmup 5 > $O/bench.json     # the driver's contract command
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-large-state > $O/bench_under_rocprof.json 2> $O/kt.err
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   D=$O/pmc_$(echo $C | tr ' ' '_')
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --secondary-maxiter 0 > $D.json 2> $D.err
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $D -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-large-state --secondary-maxiter 0 > $D.json 2> $D.err
 done
 cd $R
 python - <<PY

@@ -7,7 +7,7 @@ TAG=$1
 R=$PWD
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline --secondary-maxiter 1 --solve-maxiter 100"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-large-state --secondary-maxiter 1 --solve-maxiter 100"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc -- python3 $R/bench.py $ARGS > $O/bench.json 2> $O/pmc.err
 cd $R

@@ -95,8 +95,12 @@ def main():
           "of fp64 (the north star's 1e-5 unless the column says otherwise); `branch = slack`: it passed as "
           "\"no worse than 4x the fp32 oracle's own error\", capped at 1e-3 (1e-2 for the Riccati gains and the iLQR iterate, whose forward error carries cond(G) ~ 1e4, see tests/gpu_util.py GAIN_CEILING; their backward error is reported beside them as \"gain equation residual\").  `el_*`: largest per-entry relative "
           "error with the denominator floored at 1e-6 x max|ref| (p99.9 beside it).\n")
-    print(f"{len(recs)} assertions, {on_tol} on the tolerance branch, {len(recs) - on_tol} on the slack branch, "
-          f"{sum(1 for r in recs if not r.get('passed', True))} failed.\n")
+    info = [r for r in recs if r["branch"] == "info"]
+    n_slack = sum(1 for r in recs if r["branch"] == "slack")
+    print(f"{len(recs)} records: {on_tol} assertions on the tolerance branch, {n_slack} on the slack branch, "
+          f"{sum(1 for r in recs if r['branch'] != 'info' and not r.get('passed', True))} failed; {len(info)} recorded for "
+          f"information (not asserted), of which {sum(1 for r in info if not r.get('passed', True))} are above their "
+          "recorded bar (the round-2 fixed 1e-4 bar of the end-to-end bilevel gradient: listed as **above bar** below).\n")
     loose_table(recs)
     by_cfg = OrderedDict()
     for r in recs:
@@ -109,7 +113,7 @@ def main():
             test = r.get("test", "").split("::")[-1]
             el_h = f"{fmt(r.get('el_hip'))} ({fmt(r.get('el_hip_p999'))})" if "el_hip" in r else "—"
             el_o = f"{fmt(r.get('el_o32'))} ({fmt(r.get('el_o32_p999'))})" if "el_o32" in r else "—"
-            flag = "" if r.get("passed", True) else " **FAILED**"
+            flag = "" if r.get("passed", True) else (" **above bar**" if r["branch"] == "info" else " **FAILED**")
             print(f"| {test} | {r['stage']}{flag} | {fmt(r['e_hip'])} | {fmt(r.get('e_o32'))} | {fmt(r['tol'])} | "
                   f"{fmt(r['tol_used'])} | {r['branch']} | {el_h} | {el_o} | {r.get('entries', '')} |")
         print()

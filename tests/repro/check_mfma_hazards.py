@@ -44,7 +44,7 @@ def regs_of(text):
 
 
 class Ins:
-    __slots__ = ("line", "op", "text", "regs", "dst", "srcc", "passes", "ws", "tail")
+    __slots__ = ("line", "op", "text", "regs", "dst", "srcc", "ab", "passes", "ws", "tail")
 
     def __init__(self, line, text):
         self.line, self.text = line, text
@@ -52,11 +52,12 @@ class Ins:
         self.op = body.split()[0] if body else ""
         self.regs = regs_of(body[len(self.op):])
         self.passes = PASSES.get(self.op, 0)
-        self.dst = self.srcc = self.tail = set()
+        self.dst = self.srcc = self.tail = self.ab = set()
         if self.op.startswith("v_mfma") or self.op.startswith("v_smfma"):
             ops = [o.strip() for o in body[len(self.op):].split(",")]
             self.dst = regs_of(ops[0])
             self.srcc = regs_of(ops[3]) if len(ops) > 3 else set()
+            self.ab = (regs_of(ops[1]) if len(ops) > 1 else set()) | (regs_of(ops[2]) if len(ops) > 2 else set())
             if not self.passes:
                 self.passes = 16          # unknown matrix instruction: assume the longest
             hi = max(r for _, r in self.dst)
@@ -126,9 +127,12 @@ def check(path, strict=False):
                 if c.dst and c.dst == mf.dst and c.srcc == mf.dst:
                     continue         # accumulate chain on the same registers: handled by the matrix pipe, and from
                                      # here on this younger instruction is the one in flight
-                if c.dst and not (c.regs & mf.tail) - c.srcc:
-                    pass             # another matrix instruction takes the registers as its addend only: the matrix
-                                     # pipe orders the two (hipcc's own straight-line code does this every k-step)
+                if c.dst and not (c.regs & mf.tail) & c.ab:
+                    pass             # another matrix instruction takes the registers as its addend and / or as its
+                                     # own destination only (an accumulation chain hipcc renamed: d1 = mfma(a, b, d0);
+                                     # d0 = mfma(a', b', d1)): the matrix pipe is in order, it orders the addend read
+                                     # and the later write behind the earlier write (hipcc's own straight-line code
+                                     # does this every k-step).  A / B operand reads are NOT exempt.
                 elif c.regs & mf.tail:
                     bad.append((path, name, mf.line, mf.op, c.line, c.text.split(";")[0].strip(), ws, need))
                     continue
