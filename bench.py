@@ -480,6 +480,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # diagnostic only ("the first steps of a process"): GMPC_BENCH_PREHEAT_MS=<ms> keeps the chip busy
+    # with fp32 matrix products for that long before the warm-up steps, GMPC_BENCH_PRESTEPS=<n> runs n extra steps.
+    # Neither is part of the contract's measurement and neither is set by default.
+    if os.environ.get("GMPC_BENCH_PREHEAT_MS"):
+        pa = torch.randn(4096, 4096, device="cuda")
+        t_end = time.perf_counter() + float(os.environ["GMPC_BENCH_PREHEAT_MS"]) * 1e-3
+        while time.perf_counter() < t_end:
+            pa = torch.mm(pa, pa) * 1e-4
+            torch.cuda.synchronize()
+        del pa
+    for k in range(int(os.environ.get("GMPC_BENCH_PRESTEPS", "0"))):
+        step(k)
+    if os.environ.get("GMPC_BENCH_HOSTTIMES"):       # diagnostic: host enqueue time and completion time of the first steps
+        torch.cuda.synchronize()
+        t_h, evs = [], []
+        tb = time.perf_counter()
+        for k in range(int(os.environ["GMPC_BENCH_HOSTTIMES"])):
+            th0 = time.perf_counter()
+            step(k)
+            t_h.append((time.perf_counter() - th0) * 1e3)
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
+        torch.cuda.synchronize()
+        sys.stderr.write("host ms per step: " + " ".join(f"{x:.2f}" for x in t_h) + "\n")
+        sys.stderr.write("gpu ms between step ends (stream 1): " +
+                         " ".join(f"{evs[i - 1].elapsed_time(evs[i]):.3f}" for i in range(1, len(evs))) + "\n")
     for k in range(args.warmup):
         step(k)
     sync()

@@ -8,9 +8,10 @@ bilevel gradient) are compared over the whole batch.
   c4-shard    n=376 m=17 T=50  B=512   one GPU's shard of C4 (4096 over 8)
   c5-shard    n=1024 m=64 T=100 B=64   C5's shape at a batch the oracle's single sampled trajectory and
                                        the test's time budget allow (the per-GPU shard is 1024)
-  c5-full     n=1024 m=64 T=100 B=1024 the full per-GPU shard of C5, rollout + backward pass only
-Every entry point of the path runs at every shape: rollout + costs, backward pass, critic step,
-gmpc_ilqr_solve(maxiter=1), gmpc_bilevel_grad."""
+  c5-full     n=1024 m=64 T=100 B=1024 the full per-GPU shard of C5: rollout + backward pass, critic step (whole-batch
+                                       sums), gmpc_ilqr_solve(maxiter=1) with sampled trajectories (round 4)
+Every entry point of the path runs at every shape (c5-full: all but the bilevel gradient): rollout + costs, backward
+pass, critic step, gmpc_ilqr_solve(maxiter=1), gmpc_bilevel_grad."""
 
 import numpy as np
 import pytest
@@ -29,11 +30,12 @@ CONFIGS = {
     "c3-trained": (17, 6, 50, 1024, 16, 0.1),
     "c4-shard": (376, 17, 50, 512, 2, 0.3),
     "c5-shard": (1024, 64, 100, 64, 1, 0.3),
-    # C5's full per-GPU shard (1024 trajectories): rollout + backward pass only -- the batched GEMMs' block and XCD
-    # remaps depend on the batch -- with one sampled trajectory against the oracle
+    # C5's full per-GPU shard (1024 trajectories) -- the batched GEMMs' block and XCD remaps depend on the batch --:
+    # rollout + backward pass and the one-iteration solve with one / two sampled trajectories against the oracle, the
+    # critic step on its 2048 sequences as whole-batch sums; the bilevel gradient stays at c5-shard (B = 64)
     "c5-full": (1024, 64, 100, 1024, 1, 0.3),
 }
-FULL_ONLY = ("c5-full",)          # configurations that run test_rollout_and_backward_full_shape only
+FULL_ONLY = ("c5-full",)          # configurations left out of test_bilevel_grad_full_shape
 
 
 def _problem(name):
@@ -115,7 +117,7 @@ def test_rollout_and_backward_full_shape(name):
         eng.close()
 
 
-@pytest.mark.parametrize("name", [c for c in CONFIGS if c not in FULL_ONLY])
+@pytest.mark.parametrize("name", list(CONFIGS))
 def test_critic_step_full_shape(name):
     """The critic half of the metric's step on 2B sequences (B true + the B rolled-out ones), whole batch."""
     pb, _ = _problem(name)
@@ -151,7 +153,7 @@ def test_critic_step_full_shape(name):
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["c3-trained", "c4-shard", "c5-shard"])
+@pytest.mark.parametrize("name", ["c3-trained", "c4-shard", "c5-shard", "c5-full"])
 def test_ilqr_one_iteration_full_shape(name):
     """gmpc_ilqr_solve(maxiter=1) over the whole batch; sampled trajectories against the oracle's loop."""
     pb, ns = _problem(name)
@@ -172,9 +174,12 @@ def test_ilqr_one_iteration_full_shape(name):
         same = np.isclose(r32[2], r64[2], rtol=1e-3)
         assert same.any()
         ti = torch.as_tensor(idx[same], device=out["U"].device)
-        gu.assert_parity("ilqr U", out["U"][ti].cpu().numpy(), r32[1][same], r64[1][same], tol=1e-4, ceiling=gu.GAIN_CEILING)
-        gu.assert_parity("ilqr X", out["X"][ti].cpu().numpy(), r32[0][same], r64[0][same], tol=1e-4, ceiling=gu.GAIN_CEILING)
-        gu.assert_parity("ilqr obj", out["obj"][ti].cpu().numpy(), r32[2][same], r64[2][same], tol=1e-4, ceiling=gu.GAIN_CEILING)
+        # (c5-full: at n = 1024, T = 100 the NumPy fp32 oracle's own step is 1e-2 from the fp64 one on the sampled
+        # trajectories -- the "no worse than 4 x the fp32 oracle" rule stays, its cap is 3e-2 there instead of 1e-2)
+        cap = 3e-2 if name == "c5-full" else gu.GAIN_CEILING
+        gu.assert_parity("ilqr U", out["U"][ti].cpu().numpy(), r32[1][same], r64[1][same], tol=1e-4, ceiling=cap)
+        gu.assert_parity("ilqr X", out["X"][ti].cpu().numpy(), r32[0][same], r64[0][same], tol=1e-4, ceiling=cap)
+        gu.assert_parity("ilqr obj", out["obj"][ti].cpu().numpy(), r32[2][same], r64[2][same], tol=1e-4, ceiling=cap)
     finally:
         eng.close()
 
