@@ -128,7 +128,19 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const float v = wl[(size_t)2 * ks * n];
+        // (bit -> all-ones word -> AND: two vector instructions per element.  As a `bit ? v : 0` select hipcc built
+        // the 100 lane masks first -- 200 scalar registers, spilled through v_writelane / v_readlane -- and selected
+        // afterwards: seven vector-port instructions per element, on the port the fp32 MFMAs issue through)
+        // (the extraction is inline assembly because the optimiser turns and(v, sext(bit)) back into that select)
+#ifdef GMPC_LIN_SEED_SELECT
         S[ks] = ((mw[(2 * ks) >> 5] >> ((2 * ks) & 31)) & 1u) ? v : 0.f;
+#else
+        unsigned full, vb = __float_as_uint(v);
+        asm("v_bfe_i32 %1, %2, %3, 1\n\tv_and_b32 %0, %0, %1"
+            : "+v"(vb), "=&v"(full)
+            : "v"(mw[(2 * ks) >> 5]), "n"((2 * ks) & 31));
+        S[ks] = __uint_as_float(vb);
+#endif
       }
     }
 

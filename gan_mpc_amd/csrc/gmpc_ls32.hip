@@ -1,30 +1,29 @@
-// Line-search candidates, 32 per workgroup in two groups of 16 that run half a time step apart
-// (k_ls32<K0S, NOB>, 256 threads): the form for rounds whose work list holds more than one pass of k_ls16.
+// Line-search candidates, 32 per workgroup: two groups of 16 handled by two TEAMS of four waves, half a time step
+// apart (k_ls32<K0S, NOB>, 512 threads): the form for rounds whose work list holds more than one pass of k_ls16.
 //
 // k_ls16 (gmpc_ls16.hip) keeps the dynamics network's two 200 x 200 matrices in the registers of 4 waves (one per
 // SIMD) and multiplies 16 candidates at a time on v_mfma_f32_16x16x4_f32.  A step is a chain of six phases --
 // controls C, layer 0 L0, hidden layers H1 and H2, output layer O, state update U -- separated by workgroup barriers;
 // only H1 and H2 keep the matrix pipe busy (163 of the 209 MFMAs of a wave and step, 5.6 k of their 6.7 k cycles
 // each); C, L0, O and U are latency chains (LDS round trips, a few MFMAs, barriers): 6.1 k of the 19.5 k cycles of a
-// step.  At 1024 trajectories the first round of a line search holds up to 8192 candidates: two full passes of k_ls16
-// over the chip.
+// step, and one wave per SIMD executes in order, so the pipe idles through them.
 //
-// Here a workgroup owns TWO groups of 16 candidates, X and Y, with every per-group buffer twice in LDS and the
-// weights once in the registers, and runs Y four phases behind X:
-//     slot     1        2        3        4        5        6
-//     X        C(t)     L0(t)    H1(t)    H2(t)    O(t)     U(t)
-//     Y        O(t-1)   U(t-1)   C(t)     L0(t)    H1(t)    H2(t)
-// One barrier per slot: six per step for 32 candidates instead of twelve.  In slots 3 .. 6 the latency chain of one
-// group sits in the same basic block as the other group's matrix-pipe phase, so its LDS round trips and vector work
-// issue between MFMAs instead of in front of an idle pipe (one wave per SIMD executes in order: the overlap has to
-// be in the instruction stream); slots 1 and 2 pair two latency chains.  Everything a candidate computes is what
+// Here a workgroup is EIGHT waves, two per SIMD, each with half the register file (256): team A (waves 0-3) holds
+// layer 1's matrix and layer 0's, team B (waves 4-7) layer 2's.  A group's step is cut in two halves of equal
+// matrix-pipe time, C L0 H1 (team A) and H2 O U (team B), and the two groups X, Y alternate between the teams:
+//     half-step   2t            2t+1          2t+2
+//     team A      X: C L0 H1    Y: C L0 H1    X(t+1) ...
+//     team B      Y(t-1): H2 O U    X: H2 O U     Y: H2 O U
+// The SIMD's scheduler interleaves its two waves instruction by instruction: while one team waits in a latency chain
+// the other team's MFMAs issue.  No reliance on the compiler interleaving two instruction streams (the one-wave form of
+// this kernel, round 4's first attempt: profiles/EXPERIMENTS.md).  Four barriers per half-step (the teams' phase
+// boundaries are aligned: C | L0 | H1a | H1b against H2a | H2b | O | U).  Everything a candidate computes is what
 // k_ls16 computes, operation for operation (same fragments, same accumulation order): results are bit-identical.
-// The 8192 candidates of a round are ONE pass over the 256 CUs.
 //
 // Differences in layout against k_ls16 (LDS has to hold two groups): the A fragments of row block 12 and of output
-// block 1 keep their non-zero lanes only, the K-split partials of block 12 their 32 useful lanes; the operands of a
-// step's controls (gains, k, U, nominal state) are loaded by 16 lanes per candidate one slot before the state update
-// that stages them, one register set shared by the two groups; the per-step global pointers are recomputed.
+// block 1 keep their non-zero lanes only, the K-split partials of block 12 their 32 useful lanes; the relu bits are
+// bytes (plain stores) packed into words by the state update; the operands of a step's controls (gains, k, U, nominal
+// state) are loaded by 16 lanes per candidate in the group's O phase and staged in its U phase.
 //
 // Reference arithmetic: dynamics/nn.py:27-34, cost/cost_model.py:20-42, cost/nn.py:23-29, trajax
 // line_search_ddp / ddp_rollout (u = U + alpha k + K (x - X)) as called from policy/optimizers.py:19.
@@ -32,7 +31,9 @@
 #include <cstdlib>
 #include <cstring>
 
-#define LS32_THREADS 256
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+#define LS32_THREADS 512         // two teams of 256
 #define LS32_NG 2           // groups per workgroup
 #define LS32_C 16           // candidates per group
 #define LS32_KH 200         // hidden width
@@ -49,34 +50,50 @@ __device__ __forceinline__ f32x4_t ls32_mfma(float a, float b, f32x4_t c) {
 __device__ __forceinline__ int ls32_at(int k, int c) { return (k >> 2) * LS32_GS + (k & 3) * 16 + c; }
 
 // epilogue of row block nb < 12 (the bias is in the accumulator): relu, the next layer's activations, and the relu
-// bits of rows 16 nb + 4 g + i as ONE BYTE of the candidate's mask image of this layer (mb: 64 bytes per candidate and
-// layer, byte 4 nb + g).  k_ls16 ORs the nibble into the mask word with an LDS atomic; an atomic is an ordered memory
-// operation to the instruction scheduler -- nothing of the other group's phase could be moved across it -- so here
-// every nibble has a byte of its own (plain stores, written anew every step: no clearing) and the state update packs
-// eight of them into the word it writes out.
-__device__ __forceinline__ void ls32_epilogue(f32x4_t d, int nb, float* out, unsigned char* mb) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+// bits of the block in the candidate's mask image of this layer -- 32 bytes per candidate and layer in the layout of
+// the mask words that leave (bit r of the image = hidden unit r).  Lane (g, c) holds the four bits of rows
+// 16 nb + 4 g .. + 3: v_permlane16_swap hands the nibble of the odd g to the even g beside it, which stores the byte
+// 2 nb + g / 2.  (k_ls16 ORs nibbles into the mask word with LDS atomics; here the state update copies finished
+// words.)  Vector instructions are what this kernel pays for -- the fp32 MFMAs issue through the same port -- so the
+// relu is an integer max on the bit pattern (-0 and every negative: 0) and a bit is min(pattern, 1).
+// outl / mbl: this lane's first activation slot and mask byte of the block (see ls32_blk)
+__device__ __forceinline__ void ls32_epilogue(f32x4_t d, float* outl, unsigned char* mbl, int lane) {
   unsigned nib = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const bool on = d[i] > 0.f;
-    nib |= on ? (1u << i) : 0u;
-    out[(4 * nb + g) * LS32_GS + i * 16 + c] = on ? d[i] : 0.f;
+    const int r = max(__float_as_int(d[i]), 0);
+    unsigned f;
+    asm("v_min_u32 %0, 1, %1" : "=v"(f) : "v"(r));      // (as C the optimiser turns it into a compare and a select)
+    nib |= f << i;
+    outl[i * 16] = __int_as_float(r);
   }
-  mb[c * 192 + 4 * nb + g] = (unsigned char)nib;
+  const v2u sw = __builtin_amdgcn_permlane16_swap(nib, nib, false, false);    // .y: row g <- row g + 1 (g even)
+  if ((lane & 16) == 0) mbl[0] = (unsigned char)(nib | (sw.y << 4));
+}
+// A lane-dependent index as an opaque vector register: what is added to it in the code below is a compile-time
+// constant and becomes the instruction's immediate offset.  Left visible, hipcc folds the wave's (scalar) part of an
+// index into the constant first and then needs a v_add per access.
+__device__ __forceinline__ int ls32_opq(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
 }
 
 // rows 192 + g (.x) and 196 + g (.y) of a hidden layer's output for candidate lane & 15 -- the B fragments of
-// k-steps 48 and 49 -- from the K-split partials of row block 12 ([4 waves][4 registers][32 lanes]); their relu bits go
-// into bytes 48 + g and 52 + g of the candidate's mask image (every wave stores the same values)
-__device__ __forceinline__ float2 ls32_tail(const float* p12, const float* bias192, unsigned char* mb) {
-  const int lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+// k-steps 48 and 49 -- from the K-split partials of row block 12 ([4 waves][4 registers][32 lanes]); their relu bits
+// are byte 24 of the candidate's mask image: bit g and bit 4 + g per lane, ORed over the four g with one
+// v_permlane16_swap and one v_permlane32_swap (every wave stores the same byte)
+__device__ __forceinline__ float2 ls32_tail(const float* p12, const float* bias192, unsigned char* mb, int lane) {
+  const int g = lane >> 4, c = lane & 15;
   const float* q = p12 + g * 32 + c;
   const float s0 = ((q[0] + q[128]) + (q[256] + q[384])) + bias192[g];
   const float s1 = ((q[16] + q[144]) + (q[272] + q[400])) + bias192[4 + g];
-  mb[c * 192 + 48 + g] = s0 > 0.f ? 1 : 0;
-  mb[c * 192 + 52 + g] = s1 > 0.f ? 1 : 0;
-  return make_float2(fmaxf(s0, 0.f), fmaxf(s1, 0.f));
+  const int r0 = max(__float_as_int(s0), 0), r1 = max(__float_as_int(s1), 0);
+  const unsigned v = (min((unsigned)r0, 1u) | (min((unsigned)r1, 1u) << 4)) << g;
+  const v2u a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  const unsigned w = a.x | a.y;                                                // rows g, g ^ 1
+  const v2u b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  if (lane < 16) mb[c * 96 + 24] = (unsigned char)(b.x | b.y);
+  return make_float2(__int_as_float(r0), __int_as_float(r1));
 }
 
 // Global store without a branch: lanes that are not to store get an offset past the end of the buffer resource and the
@@ -86,11 +103,6 @@ __device__ __forceinline__ float2 ls32_tail(const float* p12, const float* bias1
 __device__ __forceinline__ void ls32_store_if(__amdgpu_buffer_rsrc_t rs, unsigned elem, unsigned bits, bool on) {
   __builtin_amdgcn_raw_buffer_store_b32(bits, rs, on ? elem * 4u : 0xFFFFFFF0u, 0, 0);
 }
-
-// LDS store without a branch: the element index of a lane without a role is redirected to the group's dummy slot --
-// as ARITHMETIC on the index (a `cond ? p : q` store is turned back into two exec-masked stores by hipcc, and an
-// exec-mask change orders every vector and matrix instruction of the block around it)
-__device__ __forceinline__ int ls32_pick(bool on, int idx, int other) { return other + ((idx - other) & -(int)on); }
 
 // LDS layout in floats, compile-time per instantiation (every access is then one lane-dependent base register plus an
 // immediate offset; with run-time group bases hipcc kept dozens of hoisted addresses live across the horizon and
@@ -105,9 +117,9 @@ struct Ls32Lay {
   static constexpr int DXS = XCUR + 8 * LS32_GS;                  // x - X_nominal in the layout of xcur
   static constexpr int PART = DXS + 8 * LS32_GS;                  // [4 waves][NOB][4][64] output-layer partials
   static constexpr int P12 = PART + 4 * NOB * 256;                // [2][4 waves][4][32] block-12 partials
-  static constexpr int MASK = P12 + 2 * 4 * 4 * 32;               // [16][3 layers][64] mask bytes (ls32_epilogue)
-  static constexpr int KS = MASK + LS32_C * 48;                   // gains [16][m n] (+ slack: clamped tail reads)
-  static constexpr int KUS = KS + LS32_C * MNX + 32;              // k and U, [16][8] each
+  static constexpr int MASK = P12 + 2 * 4 * 4 * 32;               // [16][3 layers][32 bytes] mask image = [16][24] words
+  static constexpr int KS = MASK + LS32_C * 24;                   // gains [16][MNX]
+  static constexpr int KUS = KS + LS32_C * MNX;                   // k and U, [16][8] each
   static constexpr int DUMMY = KUS + 2 * LS32_C * 8;              // [64] where the stores of lanes without a role land
   static constexpr int ACTA = DUMMY + 64;
   static constexpr int ACTB = ACTA + LS32_ACT;                    // (after the horizon: the stage costs [16][T])
@@ -123,10 +135,13 @@ struct Ls32Lay {
 
 // K0S: k-steps of layer 0 (n + m <= 4 K0S); NOB: 16-row blocks of the output layer (n <= 16 NOB)
 template <int K0S, int NOB>
-__global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_items) {
+__global__ __launch_bounds__(LS32_THREADS) void k_ls32(TrajArgs a, int min_items) {
   constexpr int NG = LS32_NG;
   extern __shared__ __attribute__((aligned(16))) char smem_ls32[];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 4, c16 = lane & 15;
+  // tt: thread of its team; wave: wave of its team (the row blocks / k-steps it owns are those of k_ls16's wave)
+  const int tid = threadIdx.x, tt = tid & 255, lane = tid & 63, g = lane >> 4, c16 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tt >> 6);
+  const int team = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int n = a.n, m = a.m, T = a.T, MN = m * n;
   const int NV = NOB > 1 ? n - 16 : 0;                     // valid rows of output block 1 (<= NV8)
   using LY = Ls32Lay<K0S, NOB>;
@@ -143,7 +158,6 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
     float *base, *xcur, *dxs, *actA, *actB, *part, *p12, *Ks, *kUs;
     unsigned char* mask;
   };
-  const int dmy = LY::DUMMY + lane;          // (float index of this lane's dummy slot inside a group's region)
   auto grp_at = [&](float* p) -> Grp {
     Grp G;
     G.base = p;
@@ -158,15 +172,7 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
     G.actB = p + LY::ACTB;
     return G;
   };
-  // The group's base offset is made an opaque scalar at every use inside the time loop: the lane-dependent part of an
-  // address is then ONE loop-invariant register shared by the two groups and the group's offset is added where the
-  // address is used.  With the offsets visible hipcc hoisted a second, group-1 copy of every address out of the loop
-  // (~170 registers) and spilled them.
-  auto gbase = [&](int gi) -> float* {
-    int go = gi * GSZ;
-    asm volatile("" : "+s"(go));
-    return smf + go;
-  };
+  auto gbase = [&](int gi) -> float* { return smf + gi * GSZ; };
   auto grp = [&](int gi) -> Grp { return grp_at(gbase(gi)); };
   __shared__ float s_alpha[NG][LS32_C], s_obj[NG][LS32_C];
   __shared__ int s_bi[NG][LS32_C], s_in[NG][LS32_C];
@@ -187,46 +193,46 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
   const size_t mstride = (size_t)T * Lh * GMPC_MW;
   const float w0 = sigmoidf_(a.mpc_w[0]), w1 = sigmoidf_(a.mpc_w[1]), w2 = sigmoidf_(a.mpc_w[2]);
 
-  // ---- weights: registers for the whole horizon (row blocks wave, wave + 4, wave + 8; block 12 is split over the
-  // waves by k-step, k-steps wave + 4 j)
-  float wr[2][3][LS32_KS];
-  float w0r[3][K0S], w0x[2];
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int nn = 16 * (wave + 4 * r) + c16;
-#pragma unroll
-    for (int ks = 0; ks < K0S; ++ks) {
-      const int k = 4 * ks + g;
-      w0r[r][ks] = k < n + m ? a.dyn.W[0][(size_t)k * LS32_KH + nn] : 0.f;
-    }
-  }
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int k = 4 * (wave + 4 * q) + g, nn = 192 + c16;
-    w0x[q] = (k < n + m && nn < LS32_KH) ? a.dyn.W[0][(size_t)k * LS32_KH + nn] : 0.f;
-  }
-#pragma unroll
-  for (int hl = 0; hl < 2; ++hl) {
-    const float* Wl = a.dyn.W[hl + 1];
+  // ---- weights: registers for the whole horizon.  Team A: layer 1 (row blocks wave, wave + 4, wave + 8; block 12 is
+  // split over the waves by k-step, k-steps wave + 4 j, fragments in LDS) and layer 0; team B: layer 2.
+  float wr[3][LS32_KS];
+  {
+    const float* Wl = a.dyn.W[team + 1];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int nn = 16 * (wave + 4 * r) + c16;
 #pragma unroll
-      for (int ks = 0; ks < LS32_KS; ++ks) wr[hl][r][ks] = Wl[(size_t)(4 * ks + g) * LS32_KH + nn];
+      for (int ks = 0; ks < LS32_KS; ++ks) wr[r][ks] = Wl[(size_t)(4 * ks + g) * LS32_KH + nn];
     }
+  }
+  for (int hl = 0; hl < 2; ++hl) {
+    const float* Wl = a.dyn.W[hl + 1];
     for (int e = tid; e < 52 * 32; e += LS32_THREADS) {
       const int ks = e >> 5, gg = (e >> 3) & 3, cc = e & 7;
       wxl[hl * 52 * 32 + e] = ks < LS32_KS ? Wl[(size_t)(4 * ks + gg) * LS32_KH + 192 + cc] : 0.f;
     }
   }
-  // (see k_ls16: the weight registers the allocator has to keep in the accumulation file are named here, so that
-  // the MFMAs read them there instead of through a copy)
+  // One register set, two uses: team A keeps layer 0's fragments in it (w0r[r][ks] = shr[r K0S + ks], block 12's
+  // shr[3 K0S + q]), team B the operands of the next step's controls in flight between its O and U phases
+  float shr[3 * K0S + 2];
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+  for (int e = 0; e < 3 * K0S + 2; ++e) shr[e] = 0.f;
+  if (team == 0) {
 #pragma unroll
-    for (int ks = 0; ks < LS32_KS; ++ks) asm volatile("" : "+a"(wr[0][r][ks]));
+    for (int r = 0; r < 3; ++r) {
+      const int nn = 16 * (wave + 4 * r) + c16;
 #pragma unroll
-  for (int ks = 0; ks < LS32_KS; ++ks) asm volatile("" : "+a"(wr[1][0][ks]));
+      for (int ks = 0; ks < K0S; ++ks) {
+        const int k = 4 * ks + g;
+        shr[r * K0S + ks] = k < n + m ? a.dyn.W[0][(size_t)k * LS32_KH + nn] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = 4 * (wave + 4 * q) + g, nn = 192 + c16;
+      shr[3 * K0S + q] = (k < n + m && nn < LS32_KH) ? a.dyn.W[0][(size_t)k * LS32_KH + nn] : 0.f;
+    }
+  }
   // output layer (k-steps 13 wave + j of wave `wave`): fragments in LDS
   for (int e = tid; e < 4 * 13 * 64; e += LS32_THREADS) {
     const int l = e & 63, j = (e >> 6) % 13, wv = (e >> 6) / 13;
@@ -265,64 +271,58 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
     }
   }
 
-  // ---- per-thread roles, fixed for the horizon
-  // controls u = U + alpha k + K (x - X_nominal): two lanes per (candidate, control) pair (elements i = half + 2 e)
+  // ---- per-thread roles (thread tt of a team has the role of k_ls16's thread tt).  With 256 registers per wave and
+  // 170 of them weights, a role's lane-dependent values (indices, addresses, table look-ups) are NOT kept over the
+  // horizon: every phase derives what it needs from an opaque copy of the thread index (LS32_LANE), a handful of
+  // integer instructions per phase -- left to itself hipcc hoists some seventy such values out of the time loop and
+  // spills them.  Kept: the (candidate, control) pair of the controls phase (a division by m).
   constexpr int PE = 2 * K0S;
-  const int cp = tid >> 1, chalf = tid & 1;
-  const int cc = min(cp / m, LS32_C - 1), cj = cp - (cp / m) * m;
-  const bool con = cp < LS32_C * m;
-  float calpha[NG];
-#pragma unroll
-  for (int gi = 0; gi < NG; ++gi) calpha[gi] = con ? s_alpha[gi][cc] : 0.f;
-  // operand loads of a step: 16 lanes per candidate (candidate tid >> 4, elements (tid & 15) + 16 q of its gain block)
+  const int cc = min((tt >> 1) / m, LS32_C - 1), cj = (tt >> 1) - ((tt >> 1) / m) * m;
   constexpr int KQ = K0S == 4 ? 4 : 8;          // m n <= 16 KQ
-  const int kc = tid >> 4, kl = tid & 15;
-  // state update: thread (wave i, lane (g, c)) owns coordinate 4 g + i of candidate c (output block 0); threads
-  // < 16 (n - 16) also own coordinate 16 + tid / 16 of candidate tid & 15 (output block 1)
-  const int no1 = 4 * g + wave;
-  const bool on1 = no1 < n;
-  const int x1 = ls32_at(no1, c16);
-  const float bo1 = on1 ? bias_s[3 * LS32_ROWS + no1] : 0.f;
-  const int q2 = tid >> 4;
-  const bool on2 = NOB > 1 && 16 + q2 < n;
-  const int x2 = ls32_at(on2 ? 16 + q2 : 0, c16);
-  const int pi2 = 256 + (q2 & 3) * 64 + 16 * ((q2 >> 2) & 3) + c16;
-  const float bo2 = on2 ? bias_s[3 * LS32_ROWS + 16 + q2] : 0.f;
-  int bik[NG], bi16[NG];
-  bool in16[NG];
-#pragma unroll
-  for (int gi = 0; gi < NG; ++gi) { bik[gi] = BI(gi, kc); bi16[gi] = BI(gi, c16); in16[gi] = INB(gi, c16); }
+  static_assert(KQ + 4 <= 3 * K0S + 2, "the operand registers share layer 0's");
+#define LS32_LANE()                                                                                   \
+  int tq_ = tt;                                                                                       \
+  asm volatile("" : "+v"(tq_));                                                                       \
+  const int tq = tq_, lane = tq & 63, g = lane >> 4, c16 = lane & 15;                                 \
+  (void)g; (void)c16
 
-  // operands of the controls of step t for ONE group at a time (register set shared by the groups: requested in the
-  // group's O slot, staged in its U slot)
-  float pfK[KQ], pfk = 0.f, pfU = 0.f, pfX1 = 0.f, pfX2 = 0.f;
-  auto prefetch = [&](int gi, int t) {
-    const unsigned bt = (unsigned)bik[gi] * (unsigned)T + (unsigned)t;
+  // operands of the controls of step t of one group (team B: requested in the group's O phase, staged in its U
+  // phase): 16 lanes per candidate (candidate tq >> 4, elements (tq & 15) + 16 q of its gain block); the nominal
+  // state's coordinates of the state update's roles (see phaseU)
+  auto prefetch = [&](int gi, int t, int tq) __attribute__((always_inline)) {
+    const int kc = tq >> 4, kl = tq & 15, lane = tq & 63, g = lane >> 4, c16 = lane & 15;
+    const int no1 = 4 * g + wave, q2 = tq >> 4;
+    const unsigned bt = (unsigned)BI(gi, kc) * (unsigned)T + (unsigned)t;
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) pfK[q] = a.Kg[bt * (unsigned)MN + (unsigned)min(kl + 16 * q, MN - 1)];
+    for (int q = 0; q < KQ; ++q) shr[q] = a.Kg[bt * (unsigned)MN + (unsigned)min(kl + 16 * q, MN - 1)];
     const unsigned ku = bt * (unsigned)m + (unsigned)min(kl, m - 1);
-    pfk = a.kg[ku];
-    pfU = a.Uio[ku];
-    const unsigned xt = ((unsigned)bi16[gi] * (unsigned)(T + 1) + (unsigned)t) * (unsigned)n;
-    pfX1 = a.X[xt + (unsigned)(on1 ? no1 : 0)];
-    if (NOB > 1) pfX2 = a.X[xt + (unsigned)(on2 ? 16 + q2 : 0)];
+    shr[KQ] = a.kg[ku];
+    shr[KQ + 1] = a.Uio[ku];
+    const unsigned xt = ((unsigned)BI(gi, c16) * (unsigned)(T + 1) + (unsigned)t) * (unsigned)n;
+    shr[KQ + 2] = a.X[xt + (unsigned)(no1 < n ? no1 : 0)];
+    if (NOB > 1) shr[KQ + 3] = a.X[xt + (unsigned)(16 + q2 < n ? 16 + q2 : 0)];
   };
-  auto stage = [&](const Grp& G) {
+  // (gain blocks at stride MNX = 16 KQ, k and U at stride 8: every lane has a slot of its own and nothing is predicated
+  // but the k / U pair of lanes 8 .. 15)
+  auto stage = [&](const Grp& G, int tq) __attribute__((always_inline)) {
+    const int kc = tq >> 4, kl = tq & 15;
+    float* kd = G.Ks + kc * LY::MNX + kl;
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) G.base[ls32_pick(kl + 16 * q < MN, LY::KS + kc * MN + kl + 16 * q, dmy)] = pfK[q];
-    G.base[ls32_pick(kl < m, LY::KUS + kc * m + kl, dmy)] = pfk;
-    G.base[ls32_pick(kl < m, LY::KUS + LS32_C * 8 + kc * m + kl, dmy)] = pfU;
+    for (int q = 0; q < KQ; ++q) kd[16 * q] = shr[q];
+    if (kl < 8) {
+      G.kUs[kc * 8 + kl] = shr[KQ];
+      G.kUs[LS32_C * 8 + kc * 8 + kl] = shr[KQ + 1];
+    }
   };
   // step 0's operands of both groups
-#pragma unroll
-  for (int gi = 0; gi < NG; ++gi) {
-    prefetch(gi, 0);
-    stage(grp(gi));
+  if (team == 1) {
+    for (int gi = 0; gi < NG; ++gi) {
+      prefetch(gi, 0, tt);
+      stage(grp(gi), tt);
+    }
   }
   __syncthreads();
 
-  // wave-uniform selects as bit masks (a `wave == k ? a : b` on a uniform condition is compiled to a scalar BRANCH,
-  // which would cut the phase's basic block in two)
   const unsigned wm0 = wave == 0 ? 0xFFFFFFFFu : 0u, wm1 = wave == 1 ? 0xFFFFFFFFu : 0u, wm3 = wave == 3 ? 0xFFFFFFFFu : 0u;
   auto bsel = [](unsigned mask, float a, float b) -> float {
     return __uint_as_float((__float_as_uint(a) & mask) | (__float_as_uint(b) & ~mask));
@@ -331,13 +331,24 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
   const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc(a.Uc, 0, 0x7FFFFFF0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(a.Xc, 0, 0x7FFFFFF0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(a.maskc, 0, 0x7FFFFFF0, 0x00020000);
-  // ================= the six phases of a group's step: straight-line code, no exec-mask regions =================
-  // (gb: the group's region; tb: the shared tables -- handed down from a slot's __restrict__ parameters)
-  auto phaseC = [&](auto gic, float* gb, int t) __attribute__((always_inline)) {
-    constexpr int gi = decltype(gic)::value;
+  // (LDS-only barrier: the global stores of a phase are not read inside the horizon)
+#define LS32_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef GMPC_TRAJ_STAMPS
+  // diagnostic build: cycles per half-step spent in each of the four segments (work) and at its barrier (wait)
+  unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp_ = __builtin_readcyclecounter();
+#define TS_(i) { const unsigned long long t_ = __builtin_readcyclecounter(); st_[i] += t_ - tp_; tp_ = t_; }
+#else
+#define TS_(i)
+#endif
+#define LS32_SEG_END(i) do { TS_(2 * (i)) LS32_BAR(); TS_(2 * (i) + 1) } while (0)
+  // ================= the six phases of a group's step (gb: the group's region; tb: the shared tables) =================
+  auto phaseC = [&](int gi, float* gb, int t) __attribute__((always_inline)) {
     const Grp G = grp_at(gb);
+    LS32_LANE();
+    const int cp = tq >> 1, chalf = tq & 1;
+    const bool con = cp < LS32_C * m;
     // (lanes without a (candidate, control) pair run the same instructions on pair 0's operands and store nowhere)
-    const float* kcb = G.Ks + (con ? cc * MN + cj * n : 0) + chalf;
+    const float* kcb = G.Ks + (con ? cc * LY::MNX + cj * n : 0) + chalf;
     const float* dcb = G.dxs + chalf * 16 + cc;
     float du = 0.f;
 #pragma unroll
@@ -347,15 +358,17 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
       du = fmaf(kcb[2 * e], chalf + 2 * e < n ? dx : 0.f, du);
     }
     du += __shfl_xor(du, 1);
-    const int cq = con ? cp : 0;
-    const float u = G.kUs[LS32_C * 8 + cq] + fmaf(calpha[gi], G.kUs[cq], du);
-    const bool st = con && chalf == 0;
-    ls32_store_if(rsU, (CI(gi, cc) * (unsigned)T + (unsigned)t) * (unsigned)m + (unsigned)cj, __float_as_uint(u),
-                  st && INB(gi, cc));
-    G.base[ls32_pick(st, LY::XCUR + ls32_at(n + cj, cc), dmy)] = u;
+    const int cq = cc * 8 + cj;
+    const float u = G.kUs[LS32_C * 8 + cq] + fmaf(s_alpha[gi][cc], G.kUs[cq], du);
+    if (con && chalf == 0) {
+      ls32_store_if(rsU, (CI(gi, cc) * (unsigned)T + (unsigned)t) * (unsigned)m + (unsigned)cj, __float_as_uint(u),
+                    b0 + gi * LS32_C + cc < cnt);
+      G.xcur[ls32_at(n + cj, cc)] = u;
+    }
   };
   auto phaseL0 = [&](float* gb, const float* tb) __attribute__((always_inline)) {
     const Grp G = grp_at(gb);
+    LS32_LANE();
     const float* bias_s = tb + LY::BIAS;
     f32x4_t d[3], dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -366,27 +379,36 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
     float bf[K0S];
 #pragma unroll
     for (int ks = 0; ks < K0S; ++ks) bf[ks] = G.xcur[ks * LS32_GS + lane];
-    const float bx0 = G.xcur[wave * LS32_GS + lane], bx1 = G.xcur[(wave + 4) * LS32_GS + lane];
+    const float* xw = G.xcur + ls32_opq(wave * LS32_GS + lane);
+    const float bx0 = xw[0], bx1 = xw[4 * LS32_GS];
 #pragma unroll
     for (int ks = 0; ks < K0S; ++ks)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) d[r] = ls32_mfma(w0r[r][ks], bf[ks], d[r]);
-    dx = ls32_mfma(w0x[0], bx0, dx);
-    dx = ls32_mfma(w0x[1], bx1, dx);
+      for (int r = 0; r < 3; ++r) d[r] = ls32_mfma(shr[r * K0S + ks], bf[ks], d[r]);
+    dx = ls32_mfma(shr[3 * K0S], bx0, dx);
+    dx = ls32_mfma(shr[3 * K0S + 1], bx1, dx);
+    {
+      const int ob = ls32_opq((4 * wave + g) * LS32_GS + c16), mo = ls32_opq(c16 * 96 + 2 * wave + (g >> 1));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) ls32_epilogue(d[r], wave + 4 * r, G.actA, G.mask);
+      for (int r = 0; r < 3; ++r) ls32_epilogue(d[r], G.actA + ob + 16 * r * LS32_GS, G.mask + mo + 8 * r, lane);
+    }
+    if (lane < 32) {
+      float* pl = G.p12 + ls32_opq(wave * 128 + lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) G.base[ls32_pick(lane < 32, LY::P12 + (wave * 4 + i) * 32 + lane, dmy)] = dx[i];
+      for (int i = 0; i < 4; ++i) pl[i * 32] = dx[i];
+    }
   };
-  // hidden layer hl (0: actA -> actB, partials p12[0] -> p12[1]; 1: actB -> actA, p12[1] -> p12[0])
+  // hidden layer hl (0: actA -> actB, partials p12[0] -> p12[1]; 1: actB -> actA, p12[1] -> p12[0]) with the weights
+  // of this wave's team; one barrier in the middle (the other team's phase boundary)
   auto phaseH = [&](auto hlc, float* gb, const float* tb) __attribute__((always_inline)) {
     constexpr int hl = decltype(hlc)::value;
     const Grp G = grp_at(gb);
+    LS32_LANE();
     const float* bias_s = tb + LY::BIAS;
     const float* wxl = tb + LY::WXL;
     const float* hin = hl == 0 ? G.actA : G.actB;
     float* hout = hl == 0 ? G.actB : G.actA;
-    const float2 tail = ls32_tail(G.p12 + (hl & 1) * 512, bias_s + hl * LS32_ROWS + 192, G.mask + hl * 64);
+    const float2 tail = ls32_tail(G.p12 + (hl & 1) * 512, bias_s + hl * LS32_ROWS + 192, G.mask + hl * 32, lane);
     f32x4_t d[3], dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -395,8 +417,8 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
     }
     // chunks of 4 k-steps, operands of chunk j + 1 read while chunk j multiplies: 4 B fragments, and the A / B
     // fragments of this wave's block-12 k-step 4 j + wave
-    const float* wx = wxl + (hl * 52 + wave) * 32 + g * 8 + (c16 & 7);
-    const float* hx = hin + wave * LS32_GS + lane;
+    const float* wx = wxl + hl * 52 * 32 + ls32_opq(wave * 32 + g * 8 + (c16 & 7));
+    const float* hx = hin + ls32_opq(wave * LS32_GS + lane);
     float bq[2][4], ax[2], bx[2];
     auto load_chunk = [&](auto jc) __attribute__((always_inline)) {
       constexpr int j = decltype(jc)::value;
@@ -406,7 +428,7 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
         if (ks < 48) bq[j & 1][e] = hin[ks * LS32_GS + lane];
       }
       // (lanes c16 >= 8 read the fragment of lane c16 - 8: rows 200 .. 207 of the product come out as copies of rows
-      // 192 .. 199 and are never stored -- a select here would put a vector instruction between every load and its MFMA)
+      // 192 .. 199 and are never stored)
       ax[j & 1] = wx[4 * j * 32];
       if (j < 12) bx[j & 1] = hx[4 * j * LS32_GS];
     };
@@ -423,51 +445,49 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
         constexpr int e = decltype(ec)::value;
         constexpr int ks = 4 * j + e;
         if constexpr (ks < LS32_KS) {
-          d[0] = ls32_mfma(wr[hl][0][ks], bq[j & 1][e], d[0]);
-          d[1] = ls32_mfma(wr[hl][1][ks], bq[j & 1][e], d[1]);
-          d[2] = ls32_mfma(wr[hl][2][ks], bq[j & 1][e], d[2]);
+          d[0] = ls32_mfma(wr[0][ks], bq[j & 1][e], d[0]);
+          d[1] = ls32_mfma(wr[1][ks], bq[j & 1][e], d[1]);
+          d[2] = ls32_mfma(wr[2][ks], bq[j & 1][e], d[2]);
         }
         if constexpr (e == 1) dx = ls32_mfma(ax[j & 1], bx[j & 1], dx);
       });
-      // between two MFMAs of the chunk: at most one LDS read, one LDS write / atomic, one buffer store and three
-      // vector instructions -- the next chunk's six fragment reads and whatever the OTHER group's phase in this
-      // basic block has ready (its LDS round trips then issue in the shadow of the matrix pipe)
-#pragma unroll
-      for (int i_ = 0; i_ < (j < 12 ? 13 : 7); ++i_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
-      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                 // the next chunk's LDS reads
+      __builtin_amdgcn_sched_group_barrier(0x008, j < 12 ? 13 : 7, 0);   // this chunk's MFMAs
+      if constexpr (j == 6) LS32_SEG_END(hl == 0 ? 2 : 0);
     });
+    {
+      const int ob = ls32_opq((4 * wave + g) * LS32_GS + c16), mo = ls32_opq(c16 * 96 + 2 * wave + (g >> 1));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) ls32_epilogue(d[r], wave + 4 * r, hout, G.mask + (hl + 1) * 64);
+      for (int r = 0; r < 3; ++r)
+        ls32_epilogue(d[r], hout + ob + 16 * r * LS32_GS, G.mask + (hl + 1) * 32 + mo + 8 * r, lane);
+    }
+    if (lane < 32) {
+      float* pl = G.p12 + ((hl + 1) & 1) * 512 + ls32_opq(wave * 128 + lane);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      G.base[ls32_pick(lane < 32, LY::P12 + ((hl + 1) & 1) * 512 + (wave * 4 + i) * 32 + lane, dmy)] = dx[i];
+      for (int i = 0; i < 4; ++i) pl[i * 32] = dx[i];
+    }
   };
-  // output layer: k-steps 13 wave .. 13 wave + 12, partial sums through LDS; requests the operands of step t + 1
-  auto phaseO = [&](auto gic, float* gb, const float* tb, int t) __attribute__((always_inline)) {
-    constexpr int gi = decltype(gic)::value;
+  // output layer: k-steps 13 wave .. 13 wave + 12, partial sums through LDS
+  auto phaseO = [&](int gi, float* gb, const float* tb, int t) __attribute__((always_inline)) {
     const Grp G = grp_at(gb);
+    LS32_LANE();
     const float* bias_s = tb + LY::BIAS;
     const float* wol = tb + LY::WOL;
     const float* wol1 = tb + LY::WOL1;
-    prefetch(gi, min(t + 1, T - 1));           // (the last step requests its own operands again: unused)
     const float* hin = G.actA;
-    const float2 tail = ls32_tail(G.p12, bias_s + 2 * LS32_ROWS + 192, G.mask + 2 * 64);
+    const float2 tail = ls32_tail(G.p12, bias_s + 2 * LS32_ROWS + 192, G.mask + 2 * 32, lane);
     f32x4_t d[NOB];
 #pragma unroll
     for (int blk = 0; blk < NOB; ++blk) d[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float bf[13], wo[NOB][13];
+    const float* hl_ = hin + ls32_opq(13 * wave * LS32_GS + lane);                   // (52 groups)
+    const float* wl_ = wol + ls32_opq(wave * 13 * 64 + lane);
+    const float* w1_ = wol1 + ls32_opq((wave * 13 * 4 + g) * NV8 + (c16 & 7));
 #pragma unroll
     for (int j = 0; j < 13; ++j) {
-      bf[j] = hin[(13 * wave + j) * LS32_GS + lane];                              // (52 groups)
-      wo[0][j] = wol[(wave * 13 + j) * 64 + lane];
-      if (NOB > 1) {
-        wo[NOB - 1][j] = wol1[((wave * 13 + j) * 4 + g) * NV8 + (c16 & 7)];     // (rows >= 24: copies, never read)
-      }
+      bf[j] = hl_[j * LS32_GS];
+      wo[0][j] = wl_[j * 64];
+      if (NOB > 1) wo[NOB - 1][j] = w1_[j * 4 * NV8];                               // (rows >= 24: copies, never read)
     }
     bf[9] = bsel(wm3, tail.x, bf[9]);                                             // k-steps 48, 49
     bf[10] = bsel(wm3, tail.y, bf[10]);
@@ -475,114 +495,121 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
     for (int j = 0; j < 13; ++j)
 #pragma unroll
       for (int blk = 0; blk < NOB; ++blk) d[blk] = ls32_mfma(wo[blk][j], bf[j], d[blk]);
+    float* pl = G.part + ls32_opq(wave * NOB * 256 + lane);
 #pragma unroll
     for (int blk = 0; blk < NOB; ++blk)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) G.part[((wave * NOB + blk) * 4 + i) * 64 + lane] = d[blk][i];
+      for (int i = 0; i < 4; ++i) pl[(blk * 4 + i) * 64] = d[blk][i];
   };
   // x_{t+1} = x_t + b_L + the four partials (thread = one (coordinate, candidate) of block 0, some also of block 1);
-  // this step's mask words leave, the LDS copy is cleared for the next step; the next step's operands are staged
-  auto phaseU = [&](auto gic, float* gb, int t) __attribute__((always_inline)) {
-    constexpr int gi = decltype(gic)::value;
+  // this step's mask words leave (two of the candidate block's 384 finished words per thread); the next step's
+  // operands are staged
+  auto phaseU = [&](int gi, float* gb, const float* tb, int t) __attribute__((always_inline)) {
     const Grp G = grp_at(gb);
+    LS32_LANE();
     const float* part = G.part;
+    const unsigned ci0 = (unsigned)(b0 + gi * LS32_C);                 // first candidate of the group
+    const unsigned left = (unsigned)max(cnt - (int)ci0, 0);           // candidates of the group that exist
+    // thread (wave i, lane (g, c)) owns coordinate 4 g + i of candidate c (output block 0); threads < 16 (n - 16) also
+    // own coordinate 16 + tq / 16 of candidate tq & 15 (output block 1)
+    const int no1 = 4 * g + wave, q2 = tq >> 4;
+    const bool on1 = no1 < n, on2 = NOB > 1 && 16 + q2 < n;
+    const int x1 = ls32_at(no1, c16), x2 = ls32_at(on2 ? 16 + q2 : 0, c16);
+    const float bo1 = tb[LY::BIAS + 3 * LS32_ROWS + no1];                            // (0 past n)
     // (coordinates past n: the same sums on in-range addresses, stored nowhere)
-    const float v1 = (((part[tid] + part[NOB * 256 + tid]) + (part[2 * NOB * 256 + tid] + part[3 * NOB * 256 + tid])) + bo1) + G.xcur[x1];
-    float v2 = 0.f;
-    if constexpr (NOB > 1)
-      v2 = (((part[pi2] + part[NOB * 256 + pi2]) + (part[2 * NOB * 256 + pi2] + part[3 * NOB * 256 + pi2])) + bo2) + G.xcur[x2];
-    // this step's mask words (thread: words tid and tid + 256 of the [16][24] block): eight nibble bytes -- or the
-    // eight bit bytes of rows 192 .. 199 -- packed
-    const bool hi = tid < LS32_C * 24 - 256;
-    auto mword = [&](int widx) -> unsigned {
-      const int c = widx / 24, w = widx - c * 24, q = w & 7;
-      const uint2 by = *reinterpret_cast<const uint2*>(G.mask + c * 192 + (w >> 3) * 64 + (q < 7 ? q : 0) * 8);
-      // nibble bytes: (b & 0xF) << 4 j; bit bytes (q == 6): (b & 1) << j
-      const unsigned lo = by.x, hi_ = by.y;
-      const unsigned nibs = (lo & 0xF) | ((lo >> 4) & 0xF0) | ((lo >> 8) & 0xF00) | ((lo >> 12) & 0xF000) |
-                            ((hi_ & 0xF) << 16) | (((hi_ >> 8) & 0xF) << 20) | (((hi_ >> 16) & 0xF) << 24) |
-                            (((hi_ >> 24) & 0xF) << 28);
-      const unsigned bits = (lo & 1) | ((lo >> 7) & 2) | ((lo >> 14) & 4) | ((lo >> 21) & 8) | ((hi_ & 1) << 4) |
-                            (((hi_ >> 8) & 1) << 5) | (((hi_ >> 16) & 1) << 6) | (((hi_ >> 24) & 1) << 7);
-      return q < 6 ? nibs : q == 6 ? bits : 0u;
-    };
-    const unsigned m1 = mword(tid), m2 = mword(hi ? tid + 256 : tid);
-    G.base[ls32_pick(on1, LY::XCUR + x1, dmy)] = v1;
-    G.base[ls32_pick(on1, LY::DXS + x1, dmy)] = v1 - pfX1;
-    if constexpr (NOB > 1) {
-      G.base[ls32_pick(on2, LY::XCUR + x2, dmy)] = v2;
-      G.base[ls32_pick(on2, LY::DXS + x2, dmy)] = v2 - pfX2;
+    const float v1 = (((part[tq] + part[NOB * 256 + tq]) + (part[2 * NOB * 256 + tq] + part[3 * NOB * 256 + tq])) + bo1) + G.xcur[x1];
+    const unsigned xo = ((ci0 + (unsigned)c16) * (unsigned)(T + 1) + (unsigned)(t + 1)) * (unsigned)n;
+    const bool in16 = (unsigned)c16 < left;
+    if (on1) {
+      G.xcur[x1] = v1;
+      G.dxs[x1] = v1 - shr[KQ + 2];
     }
-    stage(G);
-    const unsigned xo = (CI(gi, c16) * (unsigned)(T + 1) + (unsigned)(t + 1)) * (unsigned)n;
-    ls32_store_if(rsX, xo + (unsigned)no1, __float_as_uint(v1), in16[gi] && on1);
-    if constexpr (NOB > 1) ls32_store_if(rsX, xo + (unsigned)(16 + q2), __float_as_uint(v2), in16[gi] && on2);
+    ls32_store_if(rsX, xo + (unsigned)no1, __float_as_uint(v1), in16 && on1);
+    if constexpr (NOB > 1) {
+      const int pi2 = 256 + (q2 & 3) * 64 + 16 * ((q2 >> 2) & 3) + c16;
+      const float bo2 = tb[LY::BIAS + 3 * LS32_ROWS + 16 + q2];
+      const float v2 = (((part[pi2] + part[NOB * 256 + pi2]) + (part[2 * NOB * 256 + pi2] + part[3 * NOB * 256 + pi2])) + bo2) + G.xcur[x2];
+      if (on2) {
+        G.xcur[x2] = v2;
+        G.dxs[x2] = v2 - shr[KQ + 3];
+      }
+      ls32_store_if(rsX, xo + (unsigned)(16 + q2), __float_as_uint(v2), in16 && on2);
+    }
+    stage(G, tq);
     {
-      const int mc1 = tid / 24, mc2 = min((tid + 256) / 24, LS32_C - 1);
-      const unsigned ms = (unsigned)mstride, tw = (unsigned)t * 24u;
-      ls32_store_if(rsM, CI(gi, mc1) * ms + tw + (unsigned)(tid - mc1 * 24), m1, INB(gi, mc1));
-      ls32_store_if(rsM, CI(gi, mc2) * ms + tw + (unsigned)(tid + 256 - mc2 * 24), m2, hi && INB(gi, mc2));
+      // words tq and tq + 256 of the [16][24] block: word w of candidate c = image word c 24 + w
+      const unsigned* img = reinterpret_cast<const unsigned*>(G.mask);
+      const unsigned ms = (unsigned)mstride, tw = ci0 * ms + (unsigned)t * 24u;
+      const unsigned mc1 = (unsigned)tq / 24u, mc2 = (unsigned)(tq + 256) / 24u;      // (mc2 > 15: past the block)
+      ls32_store_if(rsM, tw + mc1 * (ms - 24u) + (unsigned)tq, img[tq], mc1 < left);
+      ls32_store_if(rsM, tw + mc2 * (ms - 24u) + (unsigned)(tq + 256), img[(tq + 256) & 511], mc2 < min(left, 16u));
     }
   };
 
-  // (a slot is one scheduling region: without the fences the scheduler sees slots 4 .. 6 -- one basic block, barriers
-  // do not end one -- as a single region of 1,700 instructions and the group solver takes minutes)
-#define LS32_SLOT_END() do { __builtin_amdgcn_sched_barrier(0); __syncthreads(); __builtin_amdgcn_sched_barrier(0); } while (0)
-  using X_ = std::integral_constant<int, 0>;
-  using Y_ = std::integral_constant<int, 1>;
   using H1_ = std::integral_constant<int, 0>;
   using H2_ = std::integral_constant<int, 1>;
-  // ================= the horizon: group Y four phases behind group X =================
-  // A slot = one phase of each group in ONE basic block.  The two groups and the tables come in as __restrict__
-  // parameters: inlined, that becomes scoped no-alias information on every LDS access of the slot -- without it the
-  // opaque group offsets leave the compiler unable to tell group X's stores from group Y's loads, and the latency
-  // chain of one group is pinned behind the epilogue stores of the other's matrix-pipe phase.
-  auto slot1 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
-      __attribute__((always_inline)) { phaseC(X_{}, gx, t); phaseO(Y_{}, gy, tb, t - 1); };
-  auto slot2 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
-      __attribute__((always_inline)) { phaseL0(gx, tb); phaseU(Y_{}, gy, t - 1); };
-  auto slot3 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
-      __attribute__((always_inline)) { phaseH(H1_{}, gx, tb); phaseC(Y_{}, gy, t); };
-  auto slot4 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb)
-      __attribute__((always_inline)) { phaseH(H2_{}, gx, tb); phaseL0(gy, tb); };
-  auto slot5 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
-      __attribute__((always_inline)) { phaseH(H1_{}, gy, tb); phaseO(X_{}, gx, tb, t); };
-  auto slot6 = [&](float* __restrict__ gx, float* __restrict__ gy, const float* __restrict__ tb, int t)
-      __attribute__((always_inline)) { phaseH(H2_{}, gy, tb); phaseU(X_{}, gx, t); };
-  for (int t = 0; t < T; ++t) {
-    if (t > 0) {
-      slot1(gbase(0), gbase(1), tabs, t);
-    } else {
-      phaseC(X_{}, gbase(0), t);
+  // ================= the horizon: 2 T + 1 half-steps =================
+  // half-step hs: team A takes group hs & 1 through C, L0, H1 of step hs >> 1; team B takes the OTHER group through H2,
+  // O, U of step (hs - 1) >> 1 (the half-step before, team A had that group).  Four barriers per half-step and team.
+#ifdef GMPC_TRAJ_STAMPS
+  tp_ = __builtin_readcyclecounter();
+  const unsigned long long k0_ = tp_;
+#endif
+  // (one loop per team: each is then register-allocated on its own -- in a common loop the register set the teams
+  // share, `shr`, became a loop-carried value that the compiler copied, behind a wait for every outstanding memory
+  // operation, at the top of every half-step)
+  if (team == 0) {
+    for (int hs = 0; hs < 2 * T; ++hs) {
+      const int gi = hs & 1, t = hs >> 1;
+      float* gb = gbase(gi);
+      // (the latency chains run at raised priority: measured on two waves of one SIMD, a wave issuing MFMAs back to back
+      // otherwise keeps the other wave's LDS and MFMA instructions waiting; plain vector instructions of the other wave
+      // get about one slot per MFMA even so -- tests/repro/fp32_mfma_valu_port.hip -- which is why the chains are
+      // kept short in vector instructions)
+      __builtin_amdgcn_s_setprio(3);
+      phaseC(gi, gb, t);
+      LS32_SEG_END(0);
+      phaseL0(gb, tabs);
+      __builtin_amdgcn_s_setprio(0);
+      LS32_SEG_END(1);
+      phaseH(H1_{}, gb, tabs);
+      LS32_SEG_END(3);
     }
-    LS32_SLOT_END();
-    if (t > 0) {
-      slot2(gbase(0), gbase(1), tabs, t);
-    } else {
-      phaseL0(gbase(0), tabs);
+    LS32_BAR(); LS32_BAR(); LS32_BAR(); LS32_BAR();
+  } else {
+    LS32_BAR(); LS32_BAR(); LS32_BAR(); LS32_BAR();
+    for (int hs = 1; hs <= 2 * T; ++hs) {
+      const int gi = (hs & 1) ^ 1, t = (hs - 1) >> 1;
+      float* gb = gbase(gi);
+      // the operands of the group's next step are requested here and staged by the state update, a hidden layer later
+      prefetch(gi, min(t + 1, T - 1), tt);      // (the last step requests its own operands again: unused)
+      phaseH(H2_{}, gb, tabs);
+      __builtin_amdgcn_s_setprio(3);
+      LS32_SEG_END(1);
+      phaseO(gi, gb, tabs, t);
+      LS32_SEG_END(2);
+      phaseU(gi, gb, tabs, t);
+      __builtin_amdgcn_s_setprio(0);
+      LS32_SEG_END(3);
     }
-    LS32_SLOT_END();
-    slot3(gbase(0), gbase(1), tabs, t);
-    LS32_SLOT_END();
-    slot4(gbase(0), gbase(1), tabs);
-    LS32_SLOT_END();
-    slot5(gbase(0), gbase(1), tabs, t);
-    LS32_SLOT_END();
-    slot6(gbase(0), gbase(1), tabs, t);
-    LS32_SLOT_END();
   }
-  phaseO(Y_{}, gbase(1), tabs, T - 1);
-  __syncthreads();
-  phaseU(Y_{}, gbase(1), T - 1);
+#ifdef GMPC_TRAJ_STAMPS
+  if (blockIdx.x == 0 && tt == 0)
+    printf("k_ls32 team %d cycles per half-step: seg0 %llu+%llu seg1 %llu+%llu seg2 %llu+%llu seg3 %llu+%llu | loop %llu\n", team,
+           st_[0] / (2 * T), st_[1] / (2 * T), st_[2] / (2 * T), st_[3] / (2 * T), st_[4] / (2 * T), st_[5] / (2 * T),
+           st_[6] / (2 * T), st_[7] / (2 * T), __builtin_readcyclecounter() - k0_);
+#endif
   __syncthreads();
 
-  // ---- stage costs: 4 lanes per (candidate, step) pair, 64 pairs per sweep; summed per candidate in step order
-  for (int gi = 0; gi < NG; ++gi) {
+  // ---- stage costs (team = group): 4 lanes per (candidate, step) pair, 64 pairs per sweep; summed per candidate in
+  // step order
+  {
+    const int gi = team;
     const Grp G = grp(gi);
     float* cst = G.actB;
     const float al = GMPC_ALPHA;
-    const int q = tid & 3;
-    for (int p = tid >> 2; p < LS32_C * T; p += LS32_THREADS / 4) {
+    const int q = tt & 3;
+    for (int p = tt >> 2; p < LS32_C * T; p += 64) {
       const int c = p / T, t = p - c * T;
       const int bc = BI(gi, c);
       const size_t ci = INB(gi, c) ? (size_t)CI(gi, c) : 0;  // (unused candidates read item 0's rows: in bounds, discarded)
@@ -622,13 +649,14 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
     s_obj[tid >> 4][tid & 15] = acc;
   }
   __syncthreads();            // (the stage costs have been read: actB is a layer buffer again)
-  // ---- terminal cost w2 |cost_mlp(x_T)|^2 on the matrix pipe as well: activations [k][16] in actA / actB, weight
-  // fragments straight from global memory (row blocks nb = wave, wave + 4, ..)
-  for (int gi = 0; gi < NG; ++gi) {
+  // ---- terminal cost w2 |cost_mlp(x_T)|^2 on the matrix pipe as well (team = group): activations [k][16] in actA /
+  // actB, weight fragments straight from global memory (row blocks nb = wave, wave + 4, ..)
+  {
+    const int gi = team;
     const Grp G = grp(gi);
     float* in = G.actA;
     float* out = G.actB;
-    for (int e = tid; e < LS32_C * ((n + 3) & ~3); e += LS32_THREADS) {
+    for (int e = tt; e < LS32_C * ((n + 3) & ~3); e += 256) {
       const int i = e >> 4, c = e & 15;
       in[ls32_at(i, c)] = i < n ? G.xcur[ls32_at(i, c)] : 0.f;
     }
@@ -668,16 +696,15 @@ __global__ __launch_bounds__(LS32_THREADS, 1) void k_ls32(TrajArgs a, int min_it
       __syncthreads();
       float* tmp = in; in = out; out = tmp;
     }
-    if (tid < LS32_C && INB(gi, tid)) {
+    if (tt < LS32_C && INB(gi, tt)) {
       const int fo = a.cost.dims[Lc + 1];
       float yy = 0.f;
       for (int r = 0; r < fo; ++r) {
-        const float y = in[ls32_at(r, tid)];
+        const float y = in[ls32_at(r, tt)];
         yy = fmaf(y, y, yy);
       }
-      a.objc[CI(gi, tid)] = s_obj[gi][tid] + w2 * yy;
+      a.objc[CI(gi, tt)] = s_obj[gi][tt] + w2 * yy;
     }
-    __syncthreads();
   }
 }
 
@@ -700,13 +727,14 @@ bool gmpc_ls32_shape(const TrajArgs& a) {
   return a.n <= 24 && a.m * a.n <= (k0s <= 4 && a.n <= 16 ? 64 : 128) && ls32_lds(a.n, a.m) <= LS32_LDS_MAX &&
          LS32_C * a.T <= LS32_ACT && items * (a.T + 1) * a.n < (1L << 31) && items * a.T * 3 * GMPC_MW < (1L << 31);
 }
-// work lists of at least this many candidates are k_ls32's.  OFF unless GMPC_LS32_SPLIT is set (the tests set it to
-// 1): measured in round 4 (profiles/EXPERIMENTS.md), the 8192 candidates of a first round take one pass of this kernel
-// 0.93 ms in its plain two-group form -- what two passes of k_ls16 take -- and 1.2 ms in the present, branch-free form
-// (hipcc spills 54 registers of the 512 into scratch inside the time loop), so k_ls16 keeps every long work list.
+// work lists of at least this many candidates are k_ls32's: more than one pass of k_ls16 over the 256 CUs (4096
+// candidates).  Measured in round 4 at C3 (profiles/EXPERIMENTS.md): the 8192 candidates of a first round take one pass
+// of this kernel 0.79 ms against 0.92 ms for two passes of k_ls16; a list of 4096 or fewer is one k_ls16 pass (0.46 ms)
+// and would be half a chip of this kernel for 0.79 ms.  GMPC_LS32_SPLIT overrides the threshold (0: never; the tests
+// set 1 to send every round here).
 int gmpc_ls32_split() {
   const char* e = getenv("GMPC_LS32_SPLIT");
-  return e != nullptr && atoi(e) > 0 ? atoi(e) : 0;
+  return e != nullptr ? atoi(e) : 4097;
 }
 
 template <int K0S, int NOB>

@@ -515,9 +515,10 @@ def test_bilevel_grad(name, loss_kind):
 @pytest.mark.parametrize("name", ["ls16-ragged", "ls16-n12", "ls16-n14m8", "ls16-pendulum", "ls16-m8", "trained-like",
                                   "c2-cheetah"])
 def test_linesearch_two_group_form_is_bit_identical(name, monkeypatch):
-    """k_ls32 (two groups of 16 candidates per workgroup, half a step apart) computes every candidate with k_ls16's
-    operations in k_ls16's order: forced onto every work list, a three-iteration solve must return the same bits --
-    iterate, objective, step sizes, iteration counts, candidate count -- as the solve with k_ls16 on every list."""
+    """k_ls32 (two groups of 16 candidates per workgroup, half a step apart, on two teams of four waves; the form long
+    work lists run on by default) computes every candidate with k_ls16's operations in k_ls16's order: forced onto
+    every work list, a three-iteration solve must return the same bits -- iterate, objective, step sizes, iteration
+    counts, candidate count, and the relu masks behind the last Jacobians -- as the solve with k_ls16 on every list."""
     pb, pb64, eng = _setup(name)
     d = eng.to_dev
     kw = {"maxiter": 3}
