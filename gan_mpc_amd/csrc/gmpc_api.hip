@@ -16,11 +16,15 @@
 void gmpc_launch_rollout(const TrajArgs&, hipStream_t);
 typedef void (*gmpc_ls_eval_fn)(void* user, const TrajArgs&, int max_items, hipStream_t);
 int gmpc_launch_linesearch(const TrajArgs&, const LsWork&, hipStream_t, gmpc_ls_eval_fn eval = nullptr,
-                           void* user = nullptr);
+                           void* user = nullptr, const LsSplit* split = nullptr);
 void gmpc_launch_masks(int, int, int, int, const MlpDesc&, const float*, const float*, uint32_t*,
                        hipStream_t);
 int gmpc_launch_linearize(int, int, int, int, const MlpDesc&, const uint32_t*, const int*, float*,
                           hipStream_t);
+bool gmpc_linearize_regs_covers(int, int, const MlpDesc&, const LinPad&);
+int gmpc_launch_linearize_regs_list(int cap, int T, int n, int m, const MlpDesc&, const LinPad&, const uint32_t*,
+                                    const int* tlist, const int* tcount, float* AB, int grid, hipStream_t);
+bool gmpc_ls_rounds_on_ls16(const TrajArgs&);
 int gmpc_launch_linearize_regs(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
                                const int*, float*, int, int, hipStream_t, hipEvent_t mid_event = nullptr);
 int gmpc_launch_linearize_mfma(int, int, int, int, const MlpDesc&, const LinPad&, const uint32_t*,
@@ -260,6 +264,11 @@ struct gmpc_ctx {
   // stream forked after k_head2 and joined behind the sweep
   hipStream_t crit_side = nullptr;
   hipEvent_t crit_fork = nullptr, crit_join = nullptr, crit_tr = nullptr;
+  // gmpc_ilqr_solve: the Jacobian chain of the trajectories whose line search ends with its first round runs on a
+  // context-owned side stream beside the later rounds
+  hipStream_t ls_side = nullptr;
+  hipEvent_t ls_joined = nullptr;
+  LsSplit ls_split{};
 };
 
 // RAII bracket: records a start/stop event pair around one kernel launch when profiling is on
@@ -530,6 +539,9 @@ extern "C" int gmpc_destroy(gmpc_ctx* c) {
     for (int i = 0; i < GMPC_POLL_DEPTH; ++i) (void)hipEventDestroy(c->poll_ev[i]);
   }
   if (c->crit_side) (void)hipStreamDestroy(c->crit_side);
+  if (c->ls_side) (void)hipStreamDestroy(c->ls_side);
+  if (c->ls_joined) (void)hipEventDestroy(c->ls_joined);
+  if (c->ls_split.ev) (void)hipEventDestroy(c->ls_split.ev);
   if (c->crit_fork) (void)hipEventDestroy(c->crit_fork);
   if (c->crit_join) (void)hipEventDestroy(c->crit_join);
   if (c->crit_tr) (void)hipEventDestroy(c->crit_tr);
@@ -631,9 +643,13 @@ extern "C" int gmpc_rollout_cost(gmpc_ctx* c, int B, const float* x0, const floa
 }
 
 // linearise + terminal quadratisation + Riccati/adjoint sweep on (X, U)
+// lin_list / lin_join (optional, gmpc_ilqr_solve): the Jacobian chain of some of the active trajectories has been
+// started elsewhere -- the chain here covers the trajectories lin_list->llist[0 .. *lcount), and the sweep waits for
+// lin_join
 static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, const float* goal,
                          const int* active, float* K, float* k, float* grad, float* adj, float* AB,
-                         int* cont, const gmpc_ilqr_opts* opts, hipStream_t s) {
+                         int* cont, const gmpc_ilqr_opts* opts, hipStream_t s, const LsSplit* lin_list = nullptr,
+                         hipEvent_t lin_join = nullptr) {
   const gmpc_shape& sh = c->sh;
   if (c->big) {
     if (c->lin_event) HIP_TRY(hipEventRecord(c->lin_event, s));
@@ -686,6 +702,10 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     if (c->dynl) {
       gmpc_launch_dynl_jac(B, sh.T, sh.T, 0, c->dl, X, U, active, AB, s);
       c->lin_kernel = "k_dynl_jac";
+    } else if (force == 0 && lin_list != nullptr) {
+      if (gmpc_launch_linearize_regs_list(B, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, lin_list->llist, lin_list->lcount,
+                                          AB, 0, s) < 0)
+        return fail(GMPC_EINVAL, "linearize: the register-resident chain refused a shape it covers");
     } else if (force == 0 && (rc_regs = gmpc_launch_linearize_regs(B * sh.T, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks,
                                                                    active, AB, 1, 0, s, c->lin_event)) >= 0) {
       // (rc 1: the caller's event sits between the chain's full rounds and its ragged last round)
@@ -703,6 +723,7 @@ static int backward_pass(gmpc_ctx* c, int B, const float* X, const float* U, con
     }
   }
   HIP_TRY(hipGetLastError());
+  if (lin_join) HIP_TRY(hipStreamWaitEvent(s, lin_join, 0));
   if (c->lin_event && !lin_event_done) HIP_TRY(hipEventRecord(c->lin_event, s));     // gmpc_set_linearize_event
   if (!terminal_first) TRY(run_terminal());
   HIP_TRY(hipGetLastError());
@@ -818,6 +839,48 @@ extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float*
                           hipHostMallocDefault));
     for (int i = 0; i < GMPC_POLL_DEPTH; ++i) HIP_TRY(hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
   }
+  // OPT-IN (GMPC_LS_OVERLAP=1), measured in round 4 and not a gain yet (profiles/EXPERIMENTS.md): the second round of
+  // a line search is a short work list (C3: 2.8 k candidates = 176 of k_ls16's workgroups, one per CU, on 256 CUs),
+  // while a third of the trajectories are done after the first round.  Up to `cap` of those go, behind the first
+  // round's decision, to a Jacobian chain of their own on a side stream, in GMPC_EARLY_CUS workgroups of eight waves,
+  // each the whole register file of a CU -- k_ls16 needs a whole CU per workgroup too, so the two kernels share no CU --
+  // sized to finish with the second round; the main stream runs the chain of the other trajectories behind the search
+  // (C3: 12 rounds of tiles instead of 14, 1.01 ms instead of 1.15) and waits for the side stream in front of the
+  // sweep.  Same kernels on the same data, only partitioned: results are bitwise those of the single launch
+  // (tests/test_gpu_control_flow.py).  When the second round is not one pass of k_ls16 that leaves those CUs idle the
+  // early list stays empty (k_ls_split decides on the device).  The kernels of an iteration add up to 0.09 ms less,
+  // the iteration takes 0.02 ms MORE: the fork, the join and the split cost what the shorter chain saves.
+  const bool overlap_off = !(getenv("GMPC_LS_OVERLAP") && getenv("GMPC_LS_OVERLAP")[0] == '1') ||    // (per call: the
+                           getenv("GMPC_LINEARIZE") != nullptr;                                    // tests switch it)
+  constexpr int GMPC_EARLY_CUS = 80;
+  int early_cap = 0;
+  if (!overlap_off && !c->big && !c->dynl && gmpc_linearize_regs_covers(sh.n, sh.m, c->dyn, c->lp) &&
+      gmpc_ls_rounds_on_ls16(ls)) {
+    // k_ls16 takes ~9.2 us per step of the horizon (C3: 0.46 ms), a 32-row tile of the 200-wide chain 81 us on a
+    // SIMD it shares with a second wave: tiles a wave slot of the side stream finishes inside the second round
+    const int tiles_per_slot = (int)(0.1136 * (double)T);
+    early_cap = (int)((long)GMPC_EARLY_CUS * 8 * tiles_per_slot * 32 / ((long)T * n));
+    if (early_cap > B) early_cap = B;
+  }
+  const bool overlap = early_cap > 0;
+  if (overlap && !c->ls_side) {
+    TRY(dalloc(c, &c->ls_split.tlist, c->maxB));
+    TRY(dalloc(c, &c->ls_split.tcount, 1));
+    TRY(dalloc(c, &c->ls_split.llist, c->maxB));
+    TRY(dalloc(c, &c->ls_split.lcount, 1));
+    // (an ordinary stream: on a stream created with a CU mask the chain did not start before the main stream's queue
+    // had run dry, and every launch of the main stream grew an 8 us gap -- profiles/EXPERIMENTS.md, round 4)
+    HIP_TRY(hipStreamCreateWithFlags(&c->ls_side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ls_split.ev, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ls_joined, hipEventDisableTiming));
+  }
+  if (overlap) {
+    int ncu = 256;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+    c->ls_split.cap = early_cap;
+    c->ls_split.wg_max = ncu - GMPC_EARLY_CUS;
+    if (getenv("GMPC_LS_EARLY_WGMAX")) c->ls_split.wg_max = atoi(getenv("GMPC_LS_EARLY_WGMAX"));                // (diagnostic)
+  }
   for (int it = 0; it < opts->maxiter; ++it) {
     const int slot = it % GMPC_POLL_DEPTH;
     int* hc = c->hcont + (size_t)slot * c->maxB;
@@ -831,12 +894,23 @@ extern "C" int gmpc_ilqr_solve(gmpc_ctx* c, int B, const float* x0, const float*
     HIP_TRY(hipEventRecord(c->poll_ev[slot], s));
     {
       ProfScope ps(c, PROF_LINESEARCH, s);
-      if (gmpc_launch_linesearch(ls, c->lsw, s, c->dynl ? &dynl_ls_eval : nullptr, c) != 0)
+      if (gmpc_launch_linesearch(ls, c->lsw, s, c->dynl ? &dynl_ls_eval : nullptr, c,
+                                 overlap ? &c->ls_split : nullptr) != 0)
         return fail(GMPC_EINVAL, "line search: alpha_0 / alpha_min need more than %d rounds",
                     GMPC_LS_ROUNDS_MAX);
     }
+    if (overlap) {
+      HIP_TRY(hipStreamWaitEvent(c->ls_side, c->ls_split.ev, 0));
+      {
+        ProfScope ps(c, PROF_LINEARIZE, c->ls_side);
+        if (gmpc_launch_linearize_regs_list(early_cap, sh.T, sh.n, sh.m, c->dyn, c->lp, c->masks, c->ls_split.tlist,
+                                            c->ls_split.tcount, c->AB, GMPC_EARLY_CUS, c->ls_side) < 0)
+          return fail(GMPC_EINVAL, "linearize: the register-resident chain refused a shape it covers");
+      }
+      HIP_TRY(hipEventRecord(c->ls_joined, c->ls_side));
+    }
     TRY(backward_pass(c, B, c->Xs, c->Us, c->goals, c->cont, c->Ks, c->ks, c->grads, c->adjs, c->AB,
-                      c->cont, opts, s));
+                      c->cont, opts, s, overlap ? &c->ls_split : nullptr, overlap ? c->ls_joined : nullptr));
   }
   if (X) HIP_TRY(hipMemcpyAsync(X, c->Xs, B * (T + 1) * n * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (U) HIP_TRY(hipMemcpyAsync(U, c->Us, B * T * m * sizeof(float), hipMemcpyDeviceToDevice, s));

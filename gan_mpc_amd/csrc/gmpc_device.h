@@ -214,6 +214,14 @@ struct LsWork {
   int* run;                         // [maxB]
   float* objc;                      // [maxB * GMPC_LS_ITEMS]
 };
+// gmpc_launch_linesearch's optional hand-over after the first round (see there)
+struct LsSplit {
+  int* tlist; int* tcount;          // [cap] trajectories of the early chain, in index order; their number
+  int* llist; int* lcount;          // [maxB] every other active trajectory, in index order; their number
+  int cap;                          // most trajectories the early chain takes
+  int wg_max;                       // second rounds with more 16-candidate workgroups than this keep the list empty
+  hipEvent_t ev;
+};
 #define GMPC_LS_ROUNDS_MAX 40
 #define GMPC_LS_STATS 64
 

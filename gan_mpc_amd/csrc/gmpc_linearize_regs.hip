@@ -18,6 +18,7 @@
 //
 // Compile-time shape: NT row tiles (hidden width <= 32 NT) and KS k-steps (hidden width = 2 KS or
 // 2 KS - 1), all hidden layers of the same width, n + m <= 32.  Everything else runs the LDS variant.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -62,14 +63,29 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 // 128-byte segments.
 // REST: the same kernel under a second name -- the launch that runs the ragged last round on its own (launch_regs), so
 // that a kernel trace lists it on a row of its own
-template <int NT, int KS, int TAIL = 0, bool WIDE = false, bool REST = false>
-__global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linearize_regs(
+// LIST: the samples are those of the trajectories tlist[0 .. *tcount) (T each, NSamp = capacity x T): the launch that
+// runs the chain of a compacted subset of a batch (gmpc_ilqr_solve's early chain) with balanced tiles; rows of AB are
+// written at the trajectory's own place.  Its workgroups are EIGHT waves (two per SIMD, 256 registers each: the whole
+// register file of a CU), so that `grid` workgroups occupy exactly `grid` CUs and leave every other CU entirely to
+// the kernel they run beside (k_ls16 needs a whole CU per workgroup).
+// (LIST = 2: the same through ordinary four-wave workgroups -- the chain of "everything else", balanced because the
+// tiles are those of the listed trajectories only: with flags instead, a wave's share of the static split is
+// whatever its tiles happen to hold)
+template <int NT, int KS, int TAIL = 0, bool WIDE = false, bool REST = false, int LIST = 0>
+__global__ __launch_bounds__(LIST == 1 ? 2 * GMPC_THREADS : GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linearize_regs(
     int NSamp, int T, int n, int m, MlpDesc dyn, LinPad lp, const uint32_t* masks, const int* active,
-    float* AB, int ntiles, int samp_mul, int samp_add, int tile0) {
+    float* AB, int ntiles, int samp_mul, int samp_add, int tile0, const int* tlist = nullptr,
+    const int* tcount = nullptr) {
   static_assert(NT <= 8 && 2 * KS <= 32 * NT + TAIL && (TAIL == 0 || TAIL == 8), "shape");
   constexpr bool AG = GMPC_REGS_OCC(NT, TAIL) == 1;      // register half of the accumulators (mfma_fence)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* wl_s = reinterpret_cast<float*>(smem);          // W_L  [(H + pad)][n]
+  int lcount = 0;
+  if constexpr (LIST != 0) {
+    lcount = *tcount;
+    if (lcount <= 0) return;                             // (nothing was handed over this time)
+    ntiles = min(ntiles, (int)(((long)lcount * T * n + 31) / 32));
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int Lh = dyn.L - 1, nm = n + m;
@@ -104,14 +120,23 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
   // critical path -- was measured in round 3 and is not kept: 1.121 vs 1.107 ms on the same box.)
   // (tile0: first tile of this launch -- the ragged last round of a long tile list can be a launch of its own, so
   // that a caller's event between the two lets other streams use the wave slots the last round leaves idle)
-  for (int tile = tile0 + blockIdx.x * (GMPC_THREADS / 64) + wave; tile < ntiles;
-       tile += gridDim.x * (GMPC_THREADS / 64)) {
+  constexpr int WPB = (LIST == 1 ? 2 * GMPC_THREADS : GMPC_THREADS) / 64;      // waves per workgroup
+  for (int tile = tile0 + blockIdx.x * WPB + wave; tile < ntiles; tile += gridDim.x * WPB) {
     const int r0 = tile * 32;
     int R = r0 + l31;                          // this lane's stacked Jacobian row
     const bool rvalid = R < Rtot;
     if (!rvalid) R = Rtot - 1;                 // clamped reads, no writes
     const int s = R / n, irow = R - s * n;
-    const size_t sid = (size_t)s * samp_mul + samp_add;
+    size_t sid = (size_t)s * samp_mul + samp_add;
+    int Rout = R;
+    bool lvalid = rvalid;
+    if constexpr (LIST != 0) {
+      const int tb = s / T, tq = s - tb * T;
+      lvalid = rvalid && tb < lcount;
+      if (__ballot(lvalid) == 0ull) continue;
+      sid = (size_t)tlist[min(tb, lcount - 1)] * T + tq;
+      Rout = (int)sid * n + irow;
+    }
     if (active != nullptr) {
       const bool on = active[sid / T] != 0;
       if (__ballot(on && rvalid) == 0ull) continue;
@@ -345,8 +370,8 @@ __global__ __launch_bounds__(GMPC_THREADS, GMPC_REGS_OCC(NT, TAIL)) void k_linea
       }
       GMPC_STAMP(3)
       mfma_fence<AG>(acc0);
-      if (rvalid) {
-        float* dst = AB + (size_t)R * nm;
+      if (LIST != 0 ? lvalid : rvalid) {
+        float* dst = AB + (size_t)(LIST != 0 ? Rout : R) * nm;
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) {
           const int c = (rg & 3) + 8 * (rg >> 2) + 4 * half;
@@ -410,6 +435,50 @@ static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const
   hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, WIDE>), dim3(grid), dim3(GMPC_THREADS), lds, s, NSamp, T, n, m,
                      dyn, lp, masks, active, AB, ntiles, samp_mul, samp_add, 0);
   return 0;
+}
+
+// the chain of the trajectories tlist[0 .. *tcount), at most `cap` of them.  whole_cus > 0: on that many workgroups of
+// eight waves = that many whole CUs; 0: on the persistent four-wave workgroups of the ordinary launch
+template <int NT, int KS, int TAIL = 0>
+static int launch_regs_list(int cap, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp, const uint32_t* masks,
+                            const int* tlist, const int* tcount, float* AB, int whole_cus, hipStream_t s) {
+  const long Rtot = (long)cap * T * n;
+  if (Rtot >= (1L << 31) - 64 || cap < 1) return -1;
+  const int ntiles = (int)((Rtot + 31) / 32);
+  const int Lh = dyn.L - 1;
+  size_t lds = (size_t)(dyn.dims[Lh] + GMPC_LIN_PADROWS) * n * sizeof(float) + (size_t)2 * KS * 32 * sizeof(float);
+  if (TAIL > 0) lds += (size_t)(Lh - 1) * 2 * KS * 8 * sizeof(float);
+  if (lds > 64 * 1024) return -1;
+  static_assert(GMPC_REGS_OCC(NT, TAIL) == 2, "eight waves of 256 registers");
+  if (whole_cus > 0) {
+    const int grid = std::min(whole_cus, (ntiles + 7) / 8);
+    hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, false, false, 1>), dim3(grid), dim3(2 * GMPC_THREADS), lds, s,
+                       cap * T, T, n, m, dyn, lp, masks, nullptr, AB, ntiles, 1, 0, 0, tlist, tcount);
+  } else {
+    const int grid = std::min(256 * GMPC_REGS_OCC(NT, TAIL), (ntiles + 3) / 4);
+    hipLaunchKernelGGL((k_linearize_regs<NT, KS, TAIL, false, false, 2>), dim3(grid), dim3(GMPC_THREADS), lds, s,
+                       cap * T, T, n, m, dyn, lp, masks, nullptr, AB, ntiles, 1, 0, 0, tlist, tcount);
+  }
+  return 0;
+}
+int gmpc_launch_linearize_regs_list(int cap, int T, int n, int m, const MlpDesc& dyn, const LinPad& lp,
+                                    const uint32_t* masks, const int* tlist, const int* tcount, float* AB, int whole_cus,
+                                    hipStream_t s) {
+  const int H = dyn.dims[1];
+  // (the 200-wide instantiation only: the one that runs two waves per SIMD, and the only width k_ls16 serves)
+  if (H == 200 && lp.NT == 7)
+    return launch_regs_list<6, 100, 8>(cap, T, n, m, dyn, lp, masks, tlist, tcount, AB, whole_cus, s);
+  return -1;
+}
+
+// true when gmpc_launch_linearize_regs serves this (narrow) shape -- the same conditions as its dispatch below
+bool gmpc_linearize_regs_covers(int n, int m, const MlpDesc& dyn, const LinPad& lp) {
+  const int Lh = dyn.L - 1;
+  if (Lh < 2 || n + m > 32 || lp.NTF != 1 || lp.NGF != 1) return false;
+  const int H = dyn.dims[1];
+  for (int l = 1; l <= Lh; ++l)
+    if (dyn.dims[l] != H) return false;
+  return (H == 200 && lp.NT == 7) || (H == 128 && lp.NT == 4) || (H == 64 && lp.NT == 2);
 }
 
 // returns 0 on launch (1: and mid_event was recorded between its two launches), -1 when the shape is not one this

@@ -518,8 +518,62 @@ void gmpc_launch_rollout(const TrajArgs& a0, hipStream_t s) {
 // `eval` (optional): another evaluator of the candidates of a round -- the LSTM dynamics variant
 // (gmpc_dynl.hip) -- behind the same work list and the same decide / commit kernels.
 typedef void (*gmpc_ls_eval_fn)(void* user, const TrajArgs&, int max_items, hipStream_t);
+// after the first round's decision: up to split.cap of the trajectories whose line search is over go, in index order,
+// to the list of the early Jacobian chain; every other active trajectory goes to the list of the late chain.  The early
+// chain is worth its CUs only while the second round is one pass of k_ls16 that leaves them idle: with fewer than
+// cand_min candidates to come (a round of k_traj_rw, half as long) or more than `wg_max` workgroups of 16, the early
+// list stays empty.
+__global__ __launch_bounds__(1024) void k_ls_split(int B, const int* active, const int* run, int cap, int next,
+                                                   int cand_min, int wg_max, int* tlist, int* tcount, int* llist,
+                                                   int* lcount) {
+  __shared__ int s_wf[16], s_wo[16], s_bf, s_bo, s_run;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) { s_bf = 0; s_bo = 0; s_run = 0; }
+  __syncthreads();
+  int nrun = 0;
+  for (int b = tid; b < B; b += 1024) nrun += ((active == nullptr || active[b] != 0) && run[b] != 0) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) nrun += __shfl_xor(nrun, o);
+  if (lane == 0) atomicAdd(&s_run, nrun);
+  __syncthreads();
+  // (a second round below cand_min candidates is not k_ls16's: it is over long before the early chain would be)
+  const long cand2 = (long)s_run * next;
+  const int lim = (cand2 >= cand_min && (cand2 + 15) / 16 <= wg_max) ? cap : 0;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int b0 = 0; b0 < B; b0 += 1024) {
+    const int b = b0 + tid;
+    const bool on = b < B && (active == nullptr || active[b] != 0);
+    const bool fin = on && run[b] == 0;
+    const unsigned long long balf = __ballot(fin);
+    if (lane == 0) s_wf[wv] = __popcll(balf);
+    __syncthreads();
+    int pos = s_bf + __popcll(balf & below);
+    for (int w = 0; w < wv; ++w) pos += s_wf[w];
+    const bool pick = fin && pos < lim;
+    if (pick) tlist[pos] = b;
+    const bool other = on && !pick;
+    const unsigned long long balo = __ballot(other);
+    if (lane == 0) s_wo[wv] = __popcll(balo);
+    __syncthreads();
+    int po = s_bo + __popcll(balo & below);
+    for (int w = 0; w < wv; ++w) po += s_wo[w];
+    if (other) llist[po] = b;
+    __syncthreads();
+    if (tid == 0) {
+      int tf = 0, to = 0;
+      for (int w = 0; w < 16; ++w) { tf += s_wf[w]; to += s_wo[w]; }
+      s_bf += tf;
+      s_bo += to;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { *tcount = min(s_bf, lim); *lcount = s_bo; }
+}
+// `split` (optional): the caller wants to start the backward pass of the trajectories that are done after the FIRST
+// round while the later rounds -- shorter work lists that leave part of the chip idle -- are still running: their flags
+// are compacted into split->tlist, every other active trajectory into split->llist, and split->ev is recorded behind
+// that, in front of the second round.
 int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, gmpc_ls_eval_fn eval,
-                           void* user) {
+                           void* user, const LsSplit* split) {
   TrajArgs a = a0;
   const bool rw = eval == nullptr && gmpc_traj_rw_shape(a);
   if (rw) a.aw = traj_aw(a.n, a.m, a.dyn, &a.cost);
@@ -570,8 +624,18 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
     d.obj = a.obj; d.obj_step = a.obj_step; d.U_step = a.U_step; d.alpha = a.alpha;
     d.stats = w.counts + GMPC_LS_ROUNDS_MAX + 1;
     hipLaunchKernelGGL(k_ls_decide, dim3(a.B), dim3(GMPC_THREADS), 0, s, d);
+    if (r == 0 && split != nullptr) {
+      hipLaunchKernelGGL(k_ls_split, dim3(1), dim3(1024), 0, s, a.B, a.active, w.run, split->cap, GMPC_LS_NEXT,
+                         a.ls_split, split->wg_max, split->tlist, split->tcount, split->llist, split->lcount);
+      if (hipEventRecord(split->ev, s) != hipSuccess) return -2;
+    }
   }
   return 0;
+}
+// true when the later rounds of this shape's line search run on k_ls16 (16 candidates per workgroup, one per CU)
+bool gmpc_ls_rounds_on_ls16(const TrajArgs& a0) {
+  TrajArgs a = a0;
+  return gmpc_traj_rw_shape(a) && gmpc_ls16_shape(a);
 }
 void gmpc_launch_masks(int B, int n, int m, int T, const MlpDesc& dyn, const float* X,
                        const float* U, uint32_t* masks, hipStream_t s) {

@@ -246,3 +246,38 @@ def test_headline_shape_heterogeneous_stops(ls16, monkeypatch):
     if it.max() < 6:
         _noop_check(eng, pb, kw, int(it.max()))
     eng.close()
+
+
+def test_early_jacobian_chain_beside_the_later_rounds_changes_no_bit(monkeypatch):
+    """Opt-in ordering of gmpc_ilqr_solve (GMPC_LS_OVERLAP=1, gmpc_api.hip): the Jacobian chain of up to `cap` of the
+    trajectories whose line search ends with its first round runs on a side stream beside the later rounds, the chain
+    of the others behind the search, both over compacted lists -- the same kernel on the same data in two launches
+    instead of one: every output and the Jacobians of the last backward pass are bitwise those of the default single
+    launch.  Heterogeneous stops, so that stopped trajectories are exercised as well; the early list is forced
+    non-empty (GMPC_LS_EARLY_WGMAX / a second round of any size would otherwise keep it empty at 40 trajectories)."""
+    pb = _problem(21, out_scale=0.1, B=40, n=17, m=6, T=20, hidden=(200, 200, 200), cost_hidden=(128, 128), fout=10)
+    kw = {"maxiter": 6, "obj_step_threshold": 0.0007}
+    eng = gu.engine_for(pb, critic=False)
+    d = eng.to_dev
+    try:
+        B, n, m, T = pb["B"], pb["n"], pb["m"], pb["T"]
+        monkeypatch.delenv("GMPC_LS_OVERLAP", raising=False)
+        monkeypatch.setenv("GMPC_LS16_SPLIT", "1")          # (every round on k_ls16: the second round counts as one)
+        ref = eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]), kw)
+        snap = {k: ref[k].cpu().numpy().copy() for k in ("X", "U", "obj", "grad", "iterations")}
+        ab = eng.debug_buffer(5, (B, T, n, n + m)).cpu().numpy().copy()
+        n_ls = eng.linesearch_candidates()
+        monkeypatch.setenv("GMPC_LS_OVERLAP", "1")
+        for wgmax in ("1000000", None):                     # early list forced / left to k_ls_split's own rule
+            if wgmax:
+                monkeypatch.setenv("GMPC_LS_EARLY_WGMAX", wgmax)
+            else:
+                monkeypatch.delenv("GMPC_LS_EARLY_WGMAX")
+            out = eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]), kw)
+            assert eng.linesearch_candidates() == n_ls
+            for k in snap:
+                np.testing.assert_array_equal(out[k].cpu().numpy(), snap[k], err_msg=k)
+            np.testing.assert_array_equal(eng.debug_buffer(5, (B, T, n, n + m)).cpu().numpy(), ab)
+        assert len(set(snap["iterations"].tolist())) > 1
+    finally:
+        eng.close()
