@@ -281,7 +281,7 @@ __global__ __launch_bounds__(GMPC_TRAJ_THREADS, GMPC_TRAJ_MINW) void k_traj(Traj
 // ------------------------------------------------------------------------------------------------
 #define GMPC_LS_NEXT 4   // candidates queued per trajectory after a round without an accepted step
 
-__global__ void k_ls_init(int B, const int* active, float alpha_0, float alpha_min, int k_max, int* iters,
+__global__ void k_ls_init(int B, const int* active, float alpha_0, float alpha_min, int k_max, int first_min, int* iters,
                           int* run, int* cnt, int* kfirst, const int* prevk, float* alpha, float* U_step,
                           float* obj_step) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -291,7 +291,7 @@ __global__ void k_ls_init(int B, const int* active, float alpha_0, float alpha_m
   iters[b] += 1;
   if (alpha_0 > alpha_min) {
     int R = prevk[b] + 1;
-    R = R < 1 ? 1 : R;
+    R = R < first_min ? first_min : R;      // (first_min >= 1: see gmpc_launch_linesearch)
     R = R > GMPC_LS_ITEMS ? GMPC_LS_ITEMS : R;
     R = R > k_max ? k_max : R;
     run[b] = 1;
@@ -593,8 +593,25 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
   int rounds = 0;
   for (int left = k_max, r = 0; left > 0; ++r, ++rounds) left -= r == 0 ? 1 : r == 1 ? GMPC_LS_NEXT : GMPC_LS_ITEMS;
   if (rounds > GMPC_LS_ROUNDS_MAX) return -1;
+  // Size of the first round: one more candidate than the previous search accepted -- or, where a round of 16- or
+  // 32-candidate workgroups runs anyway and has room, all GMPC_LS_ITEMS of them: a pass of k_ls32 over the chip holds
+  // 8192 candidates (k_ls16: 4096) and takes the same time half empty.  At C3 the previous rule filled it to 7965 and
+  // left ~10 trajectories per iteration whose step size had grown by more than four halvings with a THIRD round of
+  // their own (a k_traj_rw pass, 0.2 - 0.4 ms for 80 candidates, in most iterations); with the full first round a
+  // third round needs 13 halvings (20 of 102,400 searches).  Which candidate is accepted does not change.
+  int first_min = 1;
+  if (ls16) {
+    static const int ncu = []() {
+      int v = 256;
+      (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0);
+      return v;
+    }();
+    const long all = (long)a.B * GMPC_LS_ITEMS;
+    const long pass = all >= a.ls32_split && ls32 ? (long)ncu * 32 : (long)ncu * 16;
+    if (all >= a.ls_split && all <= pass) first_min = GMPC_LS_ITEMS;
+  }
   hipLaunchKernelGGL(k_ls_init, dim3((a.B + 255) / 256), dim3(256), 0, s, a.B, a.active, a.alpha_0,
-                     a.alpha_min, k_max, a.iters, w.run, w.cnt, w.kfirst, w.prevk, a.alpha, a.U_step,
+                     a.alpha_min, k_max, first_min, a.iters, w.run, w.cnt, w.kfirst, w.prevk, a.alpha, a.U_step,
                      a.obj_step);
   for (int r = 0; r < rounds; ++r) {
     hipLaunchKernelGGL(k_ls_place, dim3(1), dim3(1024), 0, s, a.B, w.cnt, w.kfirst, w.item_b[0], w.item_k[0],
