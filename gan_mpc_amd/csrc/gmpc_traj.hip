@@ -587,12 +587,6 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
   // halvings allowed by trajax' loop: candidate k runs while alpha_0 / 2^k > alpha_min
   int k_max = 0;
   for (float al = a.alpha_0; al > a.alpha_min && k_max < 4096; al *= 0.5f) ++k_max;
-  // worst case: a first round of one candidate, a second of GMPC_LS_NEXT, then GMPC_LS_ITEMS per round (a third round
-  // is rare -- 0.4 % of the bench solve's candidates -- and every round enqueued costs four launches whether it
-  // finds work or not: the later rounds take all they can hold, trajax' 15 step sizes are 4 rounds instead of 5)
-  int rounds = 0;
-  for (int left = k_max, r = 0; left > 0; ++r, ++rounds) left -= r == 0 ? 1 : r == 1 ? GMPC_LS_NEXT : GMPC_LS_ITEMS;
-  if (rounds > GMPC_LS_ROUNDS_MAX) return -1;
   // Size of the first round: one more candidate than the previous search accepted -- or, where a round of 16- or
   // 32-candidate workgroups runs anyway and has room, all GMPC_LS_ITEMS of them: a pass of k_ls32 over the chip holds
   // 8192 candidates (k_ls16: 4096) and takes the same time half empty.  At C3 the previous rule filled it to 7965 and
@@ -610,6 +604,12 @@ int gmpc_launch_linesearch(const TrajArgs& a0, const LsWork& w, hipStream_t s, g
     const long pass = all >= a.ls32_split && ls32 ? (long)ncu * 32 : (long)ncu * 16;
     if (all >= a.ls_split && all <= pass) first_min = GMPC_LS_ITEMS;
   }
+  // worst case: a first round of first_min candidates, a second of GMPC_LS_NEXT, then GMPC_LS_ITEMS per round (a third
+  // round is rare and every round enqueued costs four launches whether it finds work or not: the later rounds take all
+  // they can hold; trajax' 15 step sizes are 4 rounds after a one-candidate first round, 3 after a full one)
+  int rounds = 0;
+  for (int left = k_max, r = 0; left > 0; ++r, ++rounds) left -= r == 0 ? first_min : r == 1 ? GMPC_LS_NEXT : GMPC_LS_ITEMS;
+  if (rounds > GMPC_LS_ROUNDS_MAX) return -1;
   hipLaunchKernelGGL(k_ls_init, dim3((a.B + 255) / 256), dim3(256), 0, s, a.B, a.active, a.alpha_0,
                      a.alpha_min, k_max, first_min, a.iters, w.run, w.cnt, w.kfirst, w.prevk, a.alpha, a.U_step,
                      a.obj_step);
