@@ -414,7 +414,9 @@ static int launch_regs(int NSamp, int T, int n, int m, const MlpDesc& dyn, const
   // (measured, round 3: one workgroup per CU -- 256 of the 512 registers of every SIMD left to other kernels --
   // costs 5.5 % alone (1.141 -> 1.204 ms), and the critic's kernels beside it are starved by its back-to-back
   // 64-cycle MFMAs: k_head2 0.05 -> 0.37 ms, k_lstm_bwd2 0.11 -> 0.87 ms.  The chain keeps the chip to itself.)
-  snprintf(g_last_name, sizeof(g_last_name), "k_linearize_regs<%d, %d, %d, %s>", NT, KS, TAIL, WIDE ? "true" : "false");
+  // (as rocprofv3's kernel trace prints the instantiation: REST = false, LIST = 0 for the single launch)
+  snprintf(g_last_name, sizeof(g_last_name), "k_linearize_regs<%d, %d, %d, %s, false, 0>", NT, KS, TAIL,
+           WIDE ? "true" : "false");
   const int slots = grid * 4;
   const int full = ntiles / slots, rest = ntiles - full * slots;
   static const int split_pct = []() {
