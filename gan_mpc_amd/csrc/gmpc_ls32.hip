@@ -239,7 +239,7 @@ __global__ __launch_bounds__(LS32_THREADS) void k_ls32(TrajArgs a, int min_items
     const int ks = 13 * wv + j, no = l & 15;
     wol[e] = (ks < LS32_KS && no < n) ? a.dyn.W[Lh][(size_t)(4 * ks + (l >> 4)) * n + no] : 0.f;
   }
-  if (NOB > 1)
+  if constexpr (NOB > 1)
     for (int e = tid; e < 4 * 13 * 4 * NV8; e += LS32_THREADS) {
       const int cc = e % NV8, gg = (e / NV8) & 3, ks = e / (4 * NV8);      // ks = 13 wave + j
       wol1[e] = (ks < LS32_KS && cc < NV) ? a.dyn.W[Lh][(size_t)(4 * ks + gg) * n + 16 + cc] : 0.f;
@@ -541,8 +541,9 @@ __global__ __launch_bounds__(LS32_THREADS) void k_ls32(TrajArgs a, int min_items
       const unsigned* img = reinterpret_cast<const unsigned*>(G.mask);
       const unsigned ms = (unsigned)mstride, tw = ci0 * ms + (unsigned)t * 24u;
       const unsigned mc1 = (unsigned)tq / 24u, mc2 = (unsigned)(tq + 256) / 24u;      // (mc2 > 15: past the block)
-      ls32_store_if(rsM, tw + mc1 * (ms - 24u) + (unsigned)tq, img[tq], mc1 < left);
-      ls32_store_if(rsM, tw + mc2 * (ms - 24u) + (unsigned)(tq + 256), img[(tq + 256) & 511], mc2 < min(left, 16u));
+      ls32_store_if(rsM, tw + mc1 * (ms - 24u) + (unsigned)tq, img[tq], mc1 < left);   // (mc1 <= 10)
+      ls32_store_if(rsM, tw + mc2 * (ms - 24u) + (unsigned)(tq + 256), img[(tq + 256) & 511],
+                    mc2 < (unsigned)LS32_C && mc2 < left);
     }
   };
 
