@@ -659,7 +659,7 @@ def main():
                 "ms_per_iteration": {kk: round(v[0] / max(1, int(its.max())), 4) for kk, v in prof3.items() if v[1]},
                 "linesearch_candidates": ncand,
                 "linesearch_stats": eng.linesearch_stats(),
-                "roofline": {"kernel": "k_ls16 (work lists of 1537 candidates and more) + k_traj_rw<true> (shorter ones); "
+                "roofline": {"kernel": "k_ls32 (work lists above 4096 candidates) + k_ls16 (1537 and more) + k_traj_rw<true> (shorter ones); "
                                        "place/decide kernels included in the time",
                              "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS,
                              "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4),
