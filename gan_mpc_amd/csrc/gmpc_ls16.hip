@@ -1,4 +1,4 @@
-// Line-search candidates, 16 per workgroup (k_ls16<K0S, NOB>, 256 threads): the throughput form of
+// Line-search candidates, 16 per workgroup (k_ls16<KH, K0S, NOB>, 256 threads): the throughput form of
 // k_traj_rw<true> for rounds whose work list is long.
 //
 // k_traj_rw keeps the dynamics network's matrices in the registers of 4 waves and feeds the matrix pipe a
@@ -86,9 +86,17 @@ extern "C" int gmpc_debug_abort_stats(unsigned long long* out) {
 }
 #endif
 
-// K0S: k-steps of layer 0 (n + m <= 4 K0S); NOB: 16-row blocks of the output layer (n <= 16 NOB)
-template <int K0S, int NOB>
+// KH: hidden width -- 200 (the form described above: 12 full row blocks + the K-split block 12), or 128 / 64 (round 4:
+// 8 / 4 full row blocks dealt to the four waves, no partial block, 32 / 16 k-steps per layer; everything else is the
+// same code); K0S: k-steps of layer 0 (n + m <= 4 K0S); NOB: 16-row blocks of the output layer (n <= 16 NOB)
+template <int KH, int K0S, int NOB>
 __global__ __launch_bounds__(LS16_THREADS, 1) void k_ls16(TrajArgs a) {
+  static_assert(KH == 200 || KH == 128 || KH == 64, "hidden width");
+  constexpr bool TAILB = KH == 200;                         // rows 192 .. 199: the K-split block 12
+  constexpr int NBW = KH == 200 ? 3 : KH / 64;              // full row blocks per wave (wave, wave + 4, ..)
+  constexpr int KS = KH / 4;                                // k-steps of a hidden layer
+  constexpr int NCH = (KS + 3) / 4;                         // chunks of 4 k-steps
+  constexpr int KSW = (KS + 3) / 4;                         // k-steps of the output layer per wave
   constexpr int ACT = (LS16_ROWS / 4) * LS16_GS;            // floats of one activation buffer
   extern __shared__ __attribute__((aligned(16))) char smem_ls16[];
   float* const xcur = reinterpret_cast<float*>(smem_ls16);  // rows x ; u ; 0 (layer-0 input), 8 groups
@@ -133,56 +141,60 @@ __global__ __launch_bounds__(LS16_THREADS, 1) void k_ls16(TrajArgs a) {
 
   // ---- weights: registers for the whole horizon (row blocks wave, wave + 4, wave + 8; block 12 is split
   // over the waves by k-step, k-steps wave + 4 j)
-  float wr[2][3][LS16_KS];
-  float w0r[3][K0S], w0x[2];
+  float wr[2][NBW][KS];
+  float w0r[NBW][K0S], w0x[2] = {0.f, 0.f};
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
+  for (int r = 0; r < NBW; ++r) {
     const int nn = 16 * (wave + 4 * r) + c16;
 #pragma unroll
     for (int ks = 0; ks < K0S; ++ks) {
       const int k = 4 * ks + g;
-      w0r[r][ks] = k < n + m ? a.dyn.W[0][(size_t)k * LS16_KH + nn] : 0.f;
+      w0r[r][ks] = k < n + m ? a.dyn.W[0][(size_t)k * KH + nn] : 0.f;
     }
   }
+  if constexpr (TAILB) {
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int k = 4 * (wave + 4 * q) + g, nn = 192 + c16;
-    w0x[q] = (k < n + m && nn < LS16_KH) ? a.dyn.W[0][(size_t)k * LS16_KH + nn] : 0.f;
+    for (int q = 0; q < 2; ++q) {
+      const int k = 4 * (wave + 4 * q) + g, nn = 192 + c16;
+      w0x[q] = (k < n + m && nn < KH) ? a.dyn.W[0][(size_t)k * KH + nn] : 0.f;
+    }
   }
 #pragma unroll
   for (int hl = 0; hl < 2; ++hl) {
     const float* Wl = a.dyn.W[hl + 1];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < NBW; ++r) {
       const int nn = 16 * (wave + 4 * r) + c16;
 #pragma unroll
-      for (int ks = 0; ks < LS16_KS; ++ks) wr[hl][r][ks] = Wl[(size_t)(4 * ks + g) * LS16_KH + nn];
+      for (int ks = 0; ks < KS; ++ks) wr[hl][r][ks] = Wl[(size_t)(4 * ks + g) * KH + nn];
     }
-    for (int e = tid; e < 52 * 64; e += LS16_THREADS) {
-      const int ks = e >> 6, l = e & 63, nn = 192 + (l & 15);
-      wxl[hl * 52 * 64 + e] =
-          (ks < LS16_KS && nn < LS16_KH) ? Wl[(size_t)(4 * ks + (l >> 4)) * LS16_KH + nn] : 0.f;
-    }
+    if constexpr (TAILB)
+      for (int e = tid; e < 52 * 64; e += LS16_THREADS) {
+        const int ks = e >> 6, l = e & 63, nn = 192 + (l & 15);
+        wxl[hl * 52 * 64 + e] = (ks < KS && nn < KH) ? Wl[(size_t)(4 * ks + (l >> 4)) * KH + nn] : 0.f;
+      }
   }
   // half of the 320 weight registers has to live in the accumulation file: say which half, so that the MFMAs
   // read them there (left to itself the allocator parks them there and copies each one back into the
   // architectural file in front of its MFMA: +17 cycles per MFMA for the whole layer).  After all the loads
   // have been issued: the statements below keep their order and each one waits for its operand.
+  if constexpr (TAILB) {
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < NBW; ++r)
 #pragma unroll
-    for (int ks = 0; ks < LS16_KS; ++ks) asm volatile("" : "+a"(wr[0][r][ks]));
-  // output layer (k-steps 13 wave + j of wave `wave`): fragments in LDS, the registers are taken
-  for (int e = tid; e < 4 * NOB * 13 * 64; e += LS16_THREADS) {
-    const int l = e & 63, j = (e >> 6) % 13, wb = (e >> 6) / 13;      // wb = wave * NOB + blk
-    const int ks = 13 * (wb / NOB) + j, no = 16 * (wb % NOB) + (l & 15);
-    wol[e] = (ks < LS16_KS && no < n) ? a.dyn.W[Lh][(size_t)(4 * ks + (l >> 4)) * n + no] : 0.f;
+      for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(wr[0][r][ks]));
+  }
+  // output layer (k-steps KSW wave + j of wave `wave`): fragments in LDS, the registers are taken
+  for (int e = tid; e < 4 * NOB * KSW * 64; e += LS16_THREADS) {
+    const int l = e & 63, j = (e >> 6) % KSW, wb = (e >> 6) / KSW;      // wb = wave * NOB + blk
+    const int ks = KSW * (wb / NOB) + j, no = 16 * (wb % NOB) + (l & 15);
+    wol[e] = (ks < KS && no < n) ? a.dyn.W[Lh][(size_t)(4 * ks + (l >> 4)) * n + no] : 0.f;
   }
   for (int e = tid; e < 3 * LS16_ROWS + 32; e += LS16_THREADS) {
     float v = 0.f;
     if (e < 3 * LS16_ROWS) {
       const int l = e / LS16_ROWS, j = e - l * LS16_ROWS;
-      if (j < LS16_KH) v = a.dyn.b[l][j];
+      if (j < KH) v = a.dyn.b[l][j];
     } else if (e - 3 * LS16_ROWS < n) {
       v = a.dyn.b[Lh][e - 3 * LS16_ROWS];
     }
@@ -296,9 +308,9 @@ __global__ __launch_bounds__(LS16_THREADS, 1) void k_ls16(TrajArgs a) {
     if (t + 1 < T) prefetch(t + 1);             // in flight while the network runs
     // ---- layer 0
     {
-      f32x4_t d[3], dx = {0.f, 0.f, 0.f, 0.f};
+      f32x4_t d[NBW], dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+      for (int r = 0; r < NBW; ++r) {
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + 16 * (wave + 4 * r) + 4 * g);
         d[r] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
       }
@@ -309,13 +321,17 @@ __global__ __launch_bounds__(LS16_THREADS, 1) void k_ls16(TrajArgs a) {
 #pragma unroll
       for (int ks = 0; ks < K0S; ++ks)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) d[r] = ls16_mfma(w0r[r][ks], bf[ks], d[r]);
-      dx = ls16_mfma(w0x[0], bx0, dx);
-      dx = ls16_mfma(w0x[1], bx1, dx);
+        for (int r = 0; r < NBW; ++r) d[r] = ls16_mfma(w0r[r][ks], bf[ks], d[r]);
+      if constexpr (TAILB) {
+        dx = ls16_mfma(w0x[0], bx0, dx);
+        dx = ls16_mfma(w0x[1], bx1, dx);
+      }
 #pragma unroll
-      for (int r = 0; r < 3; ++r) ls16_epilogue(d[r], wave + 4 * r, actA, mask_s);
+      for (int r = 0; r < NBW; ++r) ls16_epilogue(d[r], wave + 4 * r, actA, mask_s);
+      if constexpr (TAILB) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) part12[(wave * 4 + i) * 64 + lane] = dx[i];
+        for (int i = 0; i < 4; ++i) part12[(wave * 4 + i) * 64 + lane] = dx[i];
+      }
     }
     __syncthreads();
     TS_(1)
@@ -324,34 +340,36 @@ __global__ __launch_bounds__(LS16_THREADS, 1) void k_ls16(TrajArgs a) {
     float* hout = actB;
 #pragma unroll
     for (int hl = 0; hl < 2; ++hl) {
-      const float2 tail = ls16_tail(part12 + (hl & 1) * 1024, bias_s + hl * LS16_ROWS + 192, mask_s + hl * 8);
-      f32x4_t d[3], dx = {0.f, 0.f, 0.f, 0.f};
+      float2 tail = make_float2(0.f, 0.f);
+      if constexpr (TAILB) tail = ls16_tail(part12 + (hl & 1) * 1024, bias_s + hl * LS16_ROWS + 192, mask_s + hl * 8);
+      f32x4_t d[NBW], dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+      for (int r = 0; r < NBW; ++r) {
         const float4 bv = *reinterpret_cast<const float4*>(bias_s + (hl + 1) * LS16_ROWS + 16 * (wave + 4 * r) + 4 * g);
         d[r] = f32x4_t{bv.x, bv.y, bv.z, bv.w};
       }
-      // chunks of 4 k-steps, operands of chunk j + 1 read while chunk j multiplies: 4 B fragments, and the
+      // chunks of 4 k-steps, operands of chunk j + 1 read while chunk j multiplies: 4 B fragments, and (KH = 200) the
       // A / B fragments of this wave's block-12 k-step 4 j + wave
       const float* wx = wxl + hl * 52 * 64 + wave * 64 + lane;
       const float* hx = hin + wave * LS16_GS + lane;
-      float bq[2][4], ax[2], bx[2];
+      float bq[2][4], ax[2] = {0.f, 0.f}, bx[2] = {0.f, 0.f};
       auto load_chunk = [&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          constexpr int dummy = 0; (void)dummy;
           const int ks = 4 * j + e;
-          if (ks < 48) bq[j & 1][e] = hin[ks * LS16_GS + lane];
+          if (ks < (TAILB ? 48 : KS)) bq[j & 1][e] = hin[ks * LS16_GS + lane];
         }
-        ax[j & 1] = wx[4 * j * 64];
-        if (j < 12) bx[j & 1] = hx[4 * j * LS16_GS];
+        if constexpr (TAILB) {
+          ax[j & 1] = wx[4 * j * 64];
+          if (j < 12) bx[j & 1] = hx[4 * j * LS16_GS];
+        }
       };
       load_chunk(std::integral_constant<int, 0>{});
-      rw_static_for<13>([&](auto jc) __attribute__((always_inline)) {
+      rw_static_for<NCH>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        if constexpr (j + 1 < 13) load_chunk(std::integral_constant<int, j + 1>{});
-        if constexpr (j == 12) {
+        if constexpr (j + 1 < NCH) load_chunk(std::integral_constant<int, j + 1>{});
+        if constexpr (TAILB && j == 12) {
           bq[0][0] = tail.x;
           bq[0][1] = tail.y;
           bx[0] = wave == 0 ? tail.x : wave == 1 ? tail.y : 0.f;
@@ -359,40 +377,44 @@ __global__ __launch_bounds__(LS16_THREADS, 1) void k_ls16(TrajArgs a) {
         rw_static_for<4>([&](auto ec) __attribute__((always_inline)) {
           constexpr int e = decltype(ec)::value;
           constexpr int ks = 4 * j + e;
-          if constexpr (ks < LS16_KS) {
-            d[0] = ls16_mfma(wr[hl][0][ks], bq[j & 1][e], d[0]);
-            d[1] = ls16_mfma(wr[hl][1][ks], bq[j & 1][e], d[1]);
-            d[2] = ls16_mfma(wr[hl][2][ks], bq[j & 1][e], d[2]);
+          if constexpr (ks < KS) {
+#pragma unroll
+            for (int r = 0; r < NBW; ++r) d[r] = ls16_mfma(wr[hl][r][ks], bq[j & 1][e], d[r]);
           }
-          if constexpr (e == 1) dx = ls16_mfma(ax[j & 1], bx[j & 1], dx);
+          if constexpr (TAILB && e == 1) dx = ls16_mfma(ax[j & 1], bx[j & 1], dx);
         });
-        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                 // the next chunk's LDS reads
-        __builtin_amdgcn_sched_group_barrier(0x008, j < 12 ? 13 : 7, 0);   // this chunk's MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x100, TAILB ? 6 : 4, 0);                               // the next chunk's LDS reads
+        __builtin_amdgcn_sched_group_barrier(0x008, TAILB ? (j < 12 ? 13 : 7) : 4 * NBW, 0);         // this chunk's MFMAs
       });
 #pragma unroll
-      for (int r = 0; r < 3; ++r) ls16_epilogue(d[r], wave + 4 * r, hout, mask_s + (hl + 1) * 8);
+      for (int r = 0; r < NBW; ++r) ls16_epilogue(d[r], wave + 4 * r, hout, mask_s + (hl + 1) * 8);
+      if constexpr (TAILB) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) part12[((hl + 1) & 1) * 1024 + (wave * 4 + i) * 64 + lane] = dx[i];
+        for (int i = 0; i < 4; ++i) part12[((hl + 1) & 1) * 1024 + (wave * 4 + i) * 64 + lane] = dx[i];
+      }
       __syncthreads();
       TS_(2 + hl)
       float* tmp = hin; hin = hout; hout = tmp;
     }
     // ---- output layer: k-steps 13 wave .. 13 wave + 12, partial sums through LDS
     {
-      const float2 tail = ls16_tail(part12, bias_s + 2 * LS16_ROWS + 192, mask_s + 2 * 8);
+      float2 tail = make_float2(0.f, 0.f);
+      if constexpr (TAILB) tail = ls16_tail(part12, bias_s + 2 * LS16_ROWS + 192, mask_s + 2 * 8);
       f32x4_t d[NOB];
 #pragma unroll
       for (int blk = 0; blk < NOB; ++blk) d[blk] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      float bf[13], wo[NOB][13];
+      float bf[KSW], wo[NOB][KSW];
 #pragma unroll
-      for (int j = 0; j < 13; ++j) {
-        bf[j] = hin[(13 * wave + j) * LS16_GS + lane];                              // (52 groups)
+      for (int j = 0; j < KSW; ++j) {
+        bf[j] = hin[(KSW * wave + j) * LS16_GS + lane];                             // (KH = 200: 52 groups)
 #pragma unroll
-        for (int blk = 0; blk < NOB; ++blk) wo[blk][j] = wol[((wave * NOB + blk) * 13 + j) * 64 + lane];
+        for (int blk = 0; blk < NOB; ++blk) wo[blk][j] = wol[((wave * NOB + blk) * KSW + j) * 64 + lane];
       }
-      if (wave == 3) { bf[9] = tail.x; bf[10] = tail.y; }                           // k-steps 48, 49
+      if constexpr (TAILB) {
+        if (wave == 3) { bf[9] = tail.x; bf[10] = tail.y; }                         // k-steps 48, 49
+      }
 #pragma unroll
-      for (int j = 0; j < 13; ++j)
+      for (int j = 0; j < KSW; ++j)
 #pragma unroll
         for (int blk = 0; blk < NOB; ++blk) d[blk] = ls16_mfma(wo[blk][j], bf[j], d[blk]);
 #pragma unroll
@@ -557,9 +579,9 @@ static size_t ls16_lds(int nob, int T);
 bool gmpc_ls16_shape(const TrajArgs& a) {
   const char* e = getenv("GMPC_LS");        // read per call: the tests switch forms inside one process
   const bool off = e != nullptr && strcmp(e, "rw") == 0;
-  // (the 16-candidate form is built for three hidden layers of 200; the 128- and 64-wide register-weight
-  // rollouts keep k_traj_rw<true> for every round)
-  if (off || !gmpc_traj_rw_shape(a) || a.dyn.dims[1] != 200 || a.n + a.m > 24 || a.m > 8 || a.n > 32 ||
+  // (three hidden layers of 200, 128 or 64 -- the widths of the register-weight rollouts)
+  const int kh = a.dyn.dims[1];
+  if (off || !gmpc_traj_rw_shape(a) || (kh != 200 && kh != 128 && kh != 64) || a.n + a.m > 24 || a.m > 8 || a.n > 32 ||
       ls16_lds(a.n > 16 ? 2 : 1, a.T) > LS16_LDS_MAX)
     return false;
   for (int l = 0; l <= a.cost.L; ++l)
@@ -578,26 +600,34 @@ static size_t ls16_lds(int nob, int T) {
                     LS16_C * 128 + 32 + 2 * LS16_C * 8 + 8 * LS16_GS;
   return fl * sizeof(float);
 }
-template <int K0S, int NOB>
+template <int KH, int K0S, int NOB>
 static void ls16_launch(const TrajArgs& a, int grid, hipStream_t s) {
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ls16<K0S, NOB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ls16<KH, K0S, NOB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, LS16_LDS_MAX);
     (void)hipGetLastError();
     attr = true;
   }
-  hipLaunchKernelGGL((k_ls16<K0S, NOB>), dim3(grid), dim3(LS16_THREADS), ls16_lds(NOB, a.T), s, a);
+  hipLaunchKernelGGL((k_ls16<KH, K0S, NOB>), dim3(grid), dim3(LS16_THREADS), ls16_lds(NOB, a.T), s, a);
+}
+template <int KH>
+static void ls16_launch_kh(const TrajArgs& a, int grid, hipStream_t s) {
+  const int k0s = (a.n + a.m + 3) / 4;
+  if (a.n <= 16) {
+    if (k0s <= 4) ls16_launch<KH, 4, 1>(a, grid, s);
+    else ls16_launch<KH, 6, 1>(a, grid, s);
+  } else {
+    ls16_launch<KH, 6, 2>(a, grid, s);
+  }
 }
 
 // one workgroup per 16 work-list items; `max_items` bounds the list (the kernel reads the actual count)
 void gmpc_launch_ls16(const TrajArgs& a, long max_items, hipStream_t s) {
   const int grid = (int)((max_items + LS16_C - 1) / LS16_C);
-  const int k0s = (a.n + a.m + 3) / 4;
-  if (a.n <= 16) {
-    if (k0s <= 4) ls16_launch<4, 1>(a, grid, s);
-    else ls16_launch<6, 1>(a, grid, s);
-  } else {
-    ls16_launch<6, 2>(a, grid, s);
+  switch (a.dyn.dims[1]) {
+    case 200: ls16_launch_kh<200>(a, grid, s); break;
+    case 128: ls16_launch_kh<128>(a, grid, s); break;
+    default: ls16_launch_kh<64>(a, grid, s); break;
   }
 }

@@ -722,7 +722,7 @@ static size_t ls32_lds(int n, int m) {
 bool gmpc_ls32_shape(const TrajArgs& a) {
   const char* e = getenv("GMPC_LS");        // read per call: the tests switch forms inside one process
   if (e != nullptr && (strcmp(e, "rw") == 0 || strcmp(e, "ls16") == 0)) return false;
-  if (!gmpc_ls16_shape(a)) return false;
+  if (!gmpc_ls16_shape(a) || a.dyn.dims[1] != LS32_KH) return false;      // (the 200-wide form only)
   const int k0s = (a.n + a.m + 3) / 4;
   const long items = (long)a.B * GMPC_LS_ITEMS;
   return a.n <= 24 && a.m * a.n <= (k0s <= 4 && a.n <= 16 ? 64 : 128) && ls32_lds(a.n, a.m) <= LS32_LDS_MAX &&

@@ -33,6 +33,10 @@ SHAPES = {
     # last workgroup with unused candidates, the three instantiations (layer-0 k-steps 4 / 6, one or two row
     # blocks of the output layer)
     "ls16-ragged": (17, 6, 9, 21, dict(out_scale=0.3)),
+    # (round 4) the 128- and 64-wide instantiations of k_ls16: 8 / 4 full row blocks, no K-split block
+    "ls16-h128": (9, 3, 12, 18, dict(dyn_hidden=(128, 128, 128), cost_hidden=(32,), cost_fout=4, out_scale=0.3)),
+    "ls16-h128-n17": (17, 6, 8, 20, dict(dyn_hidden=(128, 128, 128), cost_hidden=(64, 64), cost_fout=6, out_scale=0.3)),
+    "ls16-h64": (6, 2, 9, 19, dict(dyn_hidden=(64, 64, 64), cost_hidden=(16,), cost_fout=3, out_scale=0.3)),
     "ls16-n12": (12, 4, 7, 18, dict(out_scale=0.3)),
     "ls16-n14m8": (14, 8, 5, 17, dict(out_scale=0.3)),
     "wide": (40, 9, 6, 5, dict(dyn_hidden=(256, 64), cost_hidden=(256, 100), cost_fout=32)),
@@ -283,7 +287,7 @@ def wide_linesearch(monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["ls16-ragged", "ls16-n12", "ls16-n14m8", "ls16-pendulum", "ls16-m8",
-                                  "trained-like", "rw-one-step"])
+                                  "trained-like", "rw-one-step", "ls16-h128", "ls16-h128-n17", "ls16-h64"])
 def test_linesearch_16_candidate_form(name, wide_linesearch, monkeypatch):
     """k_ls16 against the oracle's loop (two iterations: the second line search starts from masks, states and
     controls the first one committed) and against k_traj_rw<true> on the same problem."""
