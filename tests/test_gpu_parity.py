@@ -548,6 +548,39 @@ def test_linesearch_two_group_form_is_bit_identical(name, monkeypatch):
     np.testing.assert_array_equal(AB32, eng.debug_buffer(5, (B, T, n, n + m)).cpu().numpy())
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_linesearch_two_group_form_is_bit_identical_on_random_shapes(seed, monkeypatch):
+    """The same comparison on shapes drawn at random inside k_ls32's limits (n <= 24, m <= 8, n + m <= 24, m n <= 128):
+    ragged last groups (batch x candidates not a multiple of 32), both layer-0 depths, one and two output row blocks."""
+    rng = np.random.default_rng(1000 + seed)
+    while True:
+        n, m = int(rng.integers(3, 25)), int(rng.integers(1, 9))
+        if n + m <= 24 and m * n <= 128:
+            break
+    T, B = int(rng.integers(3, 14)), int(rng.integers(5, 40))
+    pb = gu.problem(n, m, T, B, seed=seed, out_scale=0.3)
+    gu.set_config(f"ls32 random seed={seed} n={n} m={m} T={T} B={B}")
+    eng = gu.engine_for(pb, critic=False)
+    d = eng.to_dev
+    kw = {"maxiter": 3}
+    try:
+        monkeypatch.setenv("GMPC_LS16_SPLIT", "1")
+        monkeypatch.setenv("GMPC_LS", "ls16")
+        ref = eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]), kw)
+        n16 = eng.linesearch_candidates()
+        snap = {key: ref[key].cpu().numpy().copy() for key in ("X", "U", "obj", "grad", "iterations")}
+        ab = eng.debug_buffer(5, (B, T, n, n + m)).cpu().numpy().copy()
+        monkeypatch.delenv("GMPC_LS")
+        monkeypatch.setenv("GMPC_LS32_SPLIT", "1")
+        out = eng.ilqr_solve(d(pb["x0"]), d(pb["U"]), d(pb["goal"]), kw)
+        assert eng.linesearch_candidates() == n16
+        for key in snap:
+            np.testing.assert_array_equal(out[key].cpu().numpy(), snap[key], err_msg=f"{key} (n={n} m={m} T={T} B={B})")
+        np.testing.assert_array_equal(eng.debug_buffer(5, (B, T, n, n + m)).cpu().numpy(), ab)
+    finally:
+        eng.close()
+
+
 def test_unsupported_shape_fails_loudly():
     from gan_mpc_amd import GmpcError
     from gan_mpc_amd.engine import Engine
